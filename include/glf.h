@@ -1,0 +1,248 @@
+/*
+ * glf.h -- C-ABI of the MI355X-native graph-Laplacian image filter.
+ *
+ * Drop-in boundary for the approximate path of the reference program
+ * hpc/image_processing (David-Wobrock/image-processing-graph-laplacian).
+ * The reference has no FFI; its boundary is the per-stage C prototypes in
+ * hpc/*.h, all of which take PETSc Mat/Vec. Here Mat/Vec become flat HIP
+ * device buffers described by the plain struct glf_mat; every entry point is
+ * extern "C", takes plain pointers and sizes, and returns an int status
+ * (0 = GLF_OK) instead of void. Each declaration cites the reference
+ * interface it replaces (paths relative to the reference root).
+ *
+ * Layout conventions (all device matrices are float32, ROW-major):
+ *   image        uint8  [height][width]            (x = idx / width is the row,
+ *                                                   y = idx % width the column, hpc/utils.c:11-19)
+ *   K_A, L_A     float  [p][p]
+ *   X, Phi_A     float  [p][ld]   ld = m rounded up to 32, columns >= m are zero
+ *   Phi          float  [N][ld]   row order GLF_ROWS_SAMPLE_FIRST or GLF_ROWS_RASTER
+ *   K_B, L_B     never stored: a GLF_MAT_KERNEL_B descriptor (image + sample table + scale)
+ *
+ * Threading: one host thread drives one context; contexts are independent.
+ * Multi-GPU: one process per GPU; the caller plugs its collectives in through
+ * glf_comm (bench.py uses torch.distributed = RCCL). Pixel rows are sharded,
+ * see glf_image_processing.
+ */
+#ifndef GLF_H
+#define GLF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLF_VERSION 100
+
+/* ---- status codes ---------------------------------------------------------- */
+enum {
+    GLF_OK = 0,
+    GLF_ERR_INVALID = -1,   /* bad argument / shape mismatch */
+    GLF_ERR_NOMEM = -2,     /* hipMalloc / malloc failed */
+    GLF_ERR_HIP = -3,       /* a HIP call or kernel launch failed */
+    GLF_ERR_NODEVICE = -4,  /* no usable gfx950 device */
+    GLF_ERR_COMM = -5,      /* a glf_comm callback failed */
+    GLF_ERR_NOCONV = -6,    /* eigensolver hit max_outer / inner limit */
+    GLF_ERR_IO = -7,        /* read_png / write_png */
+    GLF_ERR_UNSUPPORTED = -8
+};
+const char *glf_strerror(int status);
+
+/* ---- context ---------------------------------------------------------------- */
+typedef struct glf_ctx glf_ctx; /* opaque: device, stream, workspace, comm */
+
+/* Replaces InitProgram (hpc/image_processing.c:30-38: SlepcInitialize/MPI).
+ * stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL
+ * for a stream owned by the context. */
+int glf_ctx_create(glf_ctx **ctx, int device, void *hip_stream);
+int glf_ctx_destroy(glf_ctx *ctx);      /* replaces SlepcFinalize, :332 */
+int glf_ctx_synchronize(glf_ctx *ctx);
+const char *glf_ctx_last_error(const glf_ctx *ctx);
+/* Device name / CU count / memory, for reports. */
+int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *num_cus,
+                        size_t *total_mem_bytes);
+
+/* Collectives supplied by the caller (replace the MPI_Allreduce / allgather
+ * inside PETSc's VecDot, VecSum, MatMult: hpc/gram_schmidt.c:14-15,
+ * hpc/utils.c:382, hpc/inverse_power_it.c:167). Buffers are DEVICE pointers,
+ * operated in place, ordered on the context's stream. size == 1 or NULL
+ * callbacks mean "single GPU". Return 0 on success. */
+typedef struct glf_comm {
+    int rank, size;
+    int (*allreduce_sum_f32)(void *user, float *dbuf, size_t count);
+    int (*allreduce_sum_f64)(void *user, double *dbuf, size_t count);
+    void *user;
+} glf_comm;
+int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm);
+
+/* Flat device buffers (replace MatCreate/VecCreate + MatDestroy/VecDestroy). */
+int glf_malloc(glf_ctx *ctx, void **dptr, size_t bytes);
+int glf_free(glf_ctx *ctx, void *dptr);
+int glf_memcpy_h2d(glf_ctx *ctx, void *dst, const void *src, size_t bytes);
+int glf_memcpy_d2h(glf_ctx *ctx, void *dst, const void *src, size_t bytes);
+int glf_memset(glf_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* ---- matrices ----------------------------------------------------------------- */
+enum { GLF_MAT_DENSE = 0, GLF_MAT_DIAG = 1, GLF_MAT_KERNEL_B = 2 };
+enum { GLF_ROWS_NA = 0, GLF_ROWS_SAMPLE_FIRST = 1, GLF_ROWS_RASTER = 2 };
+enum { GLF_KERNEL_BILATERAL = 0, GLF_KERNEL_PHOTOMETRIC = 1, GLF_KERNEL_SPATIAL = 2 };
+
+/* Replaces PETSc Mat (MATMPIDENSE / MATMPIAIJ diagonal). */
+typedef struct glf_mat {
+    int32_t kind;        /* GLF_MAT_* */
+    int32_t row_order;   /* GLF_ROWS_* for N x m eigenvector matrices */
+    int64_t rows, cols;  /* logical shape */
+    int64_t ld;          /* floats between consecutive rows (DENSE) */
+    float *data;         /* device; DENSE: rows*ld floats; DIAG: rows floats; KERNEL_B: NULL */
+    int32_t owns_data;   /* glf_mat_destroy frees data */
+    /* generator descriptor (KERNEL_B): entry (i, col) = scale * K(sample i, pixel col) */
+    const uint8_t *img;  /* device image */
+    const float *samples;/* device float4 per sample: {row, col, value, 0} */
+    const uint8_t *mask; /* device uint8[N]: 1 at sample pixels */
+    const uint32_t *idx; /* device sample indices, ascending */
+    int32_t width, height;
+    uint32_t p;
+    float scale;         /* 1 for K_B, -alpha for L_B (hpc/laplacian.c:37-38) */
+    float h_loc, h_val;  /* hpc/affinity.c:117-118 */
+    int32_t kernel;      /* GLF_KERNEL_* (hpc/affinity.c:119-121) */
+    double *degree;      /* device double[p]: row sums of [K_A K_B] cached by
+                            glf_ComputeAffinityMatrices (hpc/laplacian.c:18-20) */
+    int32_t owns_desc;   /* glf_mat_destroy frees samples/mask/idx/degree */
+} glf_mat;
+
+int glf_mat_create_dense(glf_ctx *ctx, glf_mat *mat, int64_t rows, int64_t cols, int64_t ld);
+int glf_mat_create_diag(glf_ctx *ctx, glf_mat *mat, int64_t n);
+int glf_mat_destroy(glf_ctx *ctx, glf_mat *mat); /* MatDestroy */
+
+/* ---- host-side stages -------------------------------------------------------- */
+
+/* void Sampling(int, int, unsigned*, unsigned**)  hpc/sampling.h:1, hpc/sampling.c:6-33.
+ * *sample_indices is malloc'd; release with glf_host_free. */
+int glf_Sampling(int width, int height, unsigned *sample_size, unsigned **sample_indices);
+void glf_host_free(void *ptr);
+
+/* BuildRandomVectors, hpc/inverse_power_it.c:12-47: X0[m][p] (vector after
+ * vector) = U[0,1) from xoshiro256** seeded with splitmix64(seed). */
+int glf_random_vectors(double *X0, unsigned p, unsigned m, uint64_t seed);
+
+/* Synthetic noisy test image of the benchmark configs; not part of
+ * the reference. out: height*width bytes. */
+int glf_synth_image(uint8_t *out, int width, int height, uint64_t seed);
+
+/* ---- device stages (mirror hpc/*.h, "glf_" prefixed) -------------------------- */
+
+/* void ComputeAffinityMatrices(Mat* K_A, Mat* K_B, const png_bytep* img, int w, int h,
+ *                              unsigned p, const unsigned* idx)   hpc/affinity.h:5, hpc/affinity.c:129-262
+ * d_img: device image; sample_indices: HOST array (as in the reference).
+ * K_A: dense p x p (allocated here). K_B: KERNEL_B descriptor whose cached
+ * degree holds this rank's partial row sums of [K_A K_B] over its pixel rows,
+ * already all-reduced when a comm is set. kernel = GLF_KERNEL_*. Pass K_A == NULL
+ * to skip materialising K_A. */
+int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const uint8_t *d_img,
+                                int width, int height, unsigned sample_size,
+                                const unsigned *sample_indices, int kernel, float h_loc, float h_val);
+
+/* void ComputeLaplacianMatrix(Mat* L_A, Mat* L_B, Mat K_A, Mat K_B)  hpc/laplacian.h:3, hpc/laplacian.c:14-42
+ * L_A = alpha (diag(D_A) - K_A) dense, L_B = KERNEL_B descriptor with scale -alpha
+ * (shares K_B's tables). K_A may be NULL (entries regenerated). alpha_out optional. */
+int glf_ComputeLaplacianMatrix(glf_ctx *ctx, glf_mat *L_A, glf_mat *L_B, const glf_mat *K_A,
+                               const glf_mat *K_B, double *alpha_out);
+
+typedef struct glf_eig_stats {
+    int32_t outer_its, inner_its_total;
+    double residual;
+} glf_eig_stats;
+
+/* void InversePowerIteration(const Mat A, unsigned m, Mat* eigvecs, Mat* eigvals,
+ *                            PetscBool optiGS, PetscScalar eps)  hpc/inverse_power_it.h:3, hpc/inverse_power_it.c:86-252
+ * X0: HOST double [m][p] start block (glf_random_vectors) or NULL for seed 1.
+ * eigenvectors: dense p x m (ld = m rounded to 32), the normalised
+ * pre-orthogonalisation iterates (:171,:230); eigenvalues: DIAG m = 1/norms (:204).
+ * inner_rtol stands in for PETSc's KSP rtol default 1e-5. */
+int glf_InversePowerIteration(glf_ctx *ctx, const glf_mat *A, unsigned m, glf_mat *eigenvectors,
+                              glf_mat *eigenvalues, int optiGramSchmidt, double epsilon,
+                              double inner_rtol, int max_outer, const double *X0,
+                              glf_eig_stats *stats);
+
+/* void OrthonormaliseVecs(Vec* X, unsigned n, unsigned p, PetscScalar* norms)  hpc/gram_schmidt.h:4, hpc/gram_schmidt.c:29-64
+ * X: dense n x p (row-major, p vectors as columns); norms: HOST double[p] or NULL. */
+int glf_OrthonormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms);
+/* void NormaliseVecs(Vec* X, unsigned p, PetscScalar* norms)  hpc/gram_schmidt.h:5 */
+int glf_NormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms);
+
+/* Mat InverseDiagMat(Mat x)  hpc/utils.h (hpc/utils.c:559-586) */
+int glf_InverseDiagMat(glf_ctx *ctx, const glf_mat *x, glf_mat *inv);
+
+/* Mat Nystroem(Mat B, Mat phi_A, Mat Pi_A_Inv, unsigned N, unsigned n, unsigned p)  hpc/nystroem.h:3, hpc/nystroem.c:5-69
+ * B: KERNEL_B descriptor (L_B). phi (allocated here): N x m, SAMPLE-FIRST rows:
+ * [phi_A ; B^T (phi_A Pi_A_Inv)]. */
+int glf_Nystroem(glf_ctx *ctx, const glf_mat *B, const glf_mat *phi_A, const glf_mat *Pi_A_Inv,
+                 glf_mat *phi);
+
+/* Mat Permutation(Mat m, const unsigned* idx, unsigned p)  hpc/utils.h:18, hpc/utils.c:134-173
+ * sample-first rows -> raster rows. sample_indices: HOST. */
+int glf_Permutation(glf_ctx *ctx, const glf_mat *in, const unsigned *sample_indices,
+                    unsigned num_sample_indices, glf_mat *out);
+
+/* png_bytep* ComputeResultFromLaplacian(const png_bytep* img, Mat phi, Mat Pi, unsigned w, unsigned h)
+ * hpc/display.h:13, hpc/display.c:58-83 (+ AboveXSetY hpc/utils.c:652, OneColMat2pngbytes :492-534).
+ * phi: N x m RASTER rows; Pi: DIAG m (f(eigenvalues)); gain: 3.0 (:73).
+ * d_out: device uint8[N]; d_zf: optional device float[N] (z before clamp/cast). */
+int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf_mat *phi,
+                                   const glf_mat *Pi, unsigned width, unsigned height, float gain,
+                                   uint8_t *d_out, float *d_zf);
+
+/* ---- whole path ----------------------------------------------------------------- */
+
+typedef struct glf_options {
+    uint32_t struct_size;   /* sizeof(glf_options) */
+    uint32_t num_samples;   /* requested sample count; 0 -> width*height*sample_frac (hpc/image_processing.c:187) */
+    double sample_frac;     /* 0.01 */
+    uint32_t num_eigvals;   /* -num_eigvals; 0 or >= p -> p-1 (hpc/image_processing.c:96-108) */
+    int32_t opti_gs;        /* -opti_gs, < 1 -> 1 (:128-140) */
+    double epsilon;         /* -inv_it_epsilon, default 0.1 (:142-154) */
+    double inner_rtol;      /* 1e-5 (PETSc KSP default) */
+    int32_t max_outer;      /* safety cap on outer iterations (reference: none) */
+    uint64_t seed;          /* X0 stream */
+    float gain;             /* 3.0 hpc/display.c:73 */
+    float h_loc, h_val;     /* 40, 30 hpc/affinity.c:117-118 */
+    int32_t kernel;         /* GLF_KERNEL_BILATERAL */
+    int32_t filter_pow;     /* 1: f(Pi) = Pi (MatPow is a no-op, hpc/utils.c:721); k: Pi^k */
+} glf_options;
+void glf_options_default(glf_options *opt);
+
+typedef struct glf_stats {
+    uint32_t p, m;
+    double alpha;
+    glf_eig_stats eig;
+    /* device milliseconds (HIP events on the context's stream) */
+    float ms_affinity, ms_laplacian, ms_eigen, ms_nystroem, ms_filter, ms_total;
+    /* dominant kernel (Nystroem contraction): launches and summed device ms */
+    int32_t nystroem_launches;
+    float nystroem_kernel_ms;
+    int32_t row0, row1;     /* this rank's pixel rows */
+} glf_stats;
+
+/* ApproximationComputation, hpc/image_processing.c:183-277 (commented tail
+ * :240-275 included). d_img: device uint8[height*width], replicated on every
+ * rank. d_out: device uint8[height*width]; with a comm of size G rank g fills
+ * image rows [g*height/G, (g+1)*height/G) only. d_zf optional float[N].
+ * eigvals_out: HOST double[m] or NULL. */
+int glf_image_processing(glf_ctx *ctx, const glf_options *opt, const uint8_t *d_img, int width,
+                         int height, uint8_t *d_out, float *d_zf, double *eigvals_out,
+                         glf_stats *stats);
+
+/* ---- image I/O (host) -------------------------------------------------------------- */
+/* int read_png(const char*, png_bytep** rows, int* w, int* h)  hpc/read_img.h:3, hpc/read_img.c:9-65
+ * rows: malloc'd array of `height` malloc'd rows of `width` bytes (gray 8);
+ * RGB / RGBA are converted to gray with libpng's default rgb_to_gray weights
+ * (hpc/read_img.c:47-50). Returns 0 / -1. */
+int glf_read_png(const char *filename, uint8_t ***row_pointers, int *width, int *height);
+/* int write_png(const char*, png_bytep* rows, unsigned w, unsigned h)  hpc/write_img.h:4, hpc/write_img.c:5-53 */
+int glf_write_png(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLF_H */

@@ -1,0 +1,166 @@
+/*
+ * glf_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * fp64 CPU restatement (plain C + OpenMP) of the approximate path of the
+ * reference program hpc/ (David-Wobrock/image-processing-graph-laplacian):
+ * sampling -> bilateral affinity K_A/K_B -> Laplacian L_A/L_B -> inverse
+ * subspace iteration + classical Gram-Schmidt -> Nystroem extension ->
+ * permutation -> spectral filter.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker. The shipped HIP path never links
+ * or calls it.
+ *
+ * Pinning: the C reference needs PETSc 3.8.2 / SLEPc 3.8.2 / Elemental
+ * (hpc/Makefile:1-3), none of which exist in the build image, so it is
+ * unbuildable here (no oracle/_ref). This restatement is pinned instead by
+ * golden vectors generated from the reference's Python proof of concept
+ * (tools/gen_golden.py -> tests/golden/): sampling grid, K_A, K_B, D_A, alpha,
+ * L_A, the spectrum of L_A, the Nystroem extension and permutation. The
+ * iterative eigensolver (PETSc KSP in the reference) and the C output filter
+ * have no reference-side golden: for those two stages parity is unpinned by
+ * the reference and rests on the restatement alone (checked against LAPACK
+ * eigenpairs at tight epsilon in tests/test_oracle_golden.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).
+ */
+#ifndef GLF_ORACLE_H
+#define GLF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Kernel selector (hpc/affinity.c:117-121 picks bilateral; the other two are the
+ * commented-out alternatives hpc/affinity.c:8-57). */
+enum { ORC_BILATERAL = 0, ORC_PHOTOMETRIC = 1, ORC_SPATIAL = 2 };
+
+typedef struct orc_params {
+    double h_loc;   /* 40.0  hpc/affinity.c:118 */
+    double h_val;   /* 30.0  hpc/affinity.c:117 */
+    int kernel;     /* ORC_BILATERAL */
+} orc_params;
+
+void orc_default_params(orc_params *prm);
+
+/* hpc/sampling.c:6-33. *sample_size is rewritten to the realised grid count;
+ * *sample_indices is malloc'd (caller frees with orc_free). Returns 0 / -1. */
+int orc_sampling(int width, int height, unsigned *sample_size, unsigned **sample_indices);
+void orc_free(void *ptr);
+
+/* hpc/affinity.c:59-121: one kernel entry between two pixels. */
+double orc_kernel_entry(const orc_params *prm, double r0, double c0, double v0,
+                        double r1, double c1, double v1);
+
+/* hpc/affinity.c:129-262. img is height*width bytes, row-major (img[x][y],
+ * x = idx / width the row, y = idx % width the column, hpc/utils.c:11-19).
+ * K_A: p*p row-major. K_B: p*(N-p) row-major, columns = non-sample pixels in
+ * raster order (hpc/affinity.c:215-235); pass NULL to skip it. */
+int orc_affinity(const orc_params *prm, const uint8_t *img, int width, int height,
+                 unsigned p, const unsigned *idx, double *K_A, double *K_B);
+
+/* Row sums of [K_A K_B] without storing K_B (hpc/laplacian.c:18-20 +
+ * hpc/utils.c:364-376). rows [row0,row1) of the image only (whole image:
+ * 0,height) so a pixel-row shard can be summed on its own. D has p entries and
+ * is OVERWRITTEN with this shard's partial sum. */
+int orc_degree(const orc_params *prm, const uint8_t *img, int width, int height,
+               int row0, int row1, unsigned p, const unsigned *idx, double *D);
+
+/* hpc/laplacian.c:14-42: alpha = 1/mean(D); L_A = alpha (diag(D) - K_A).
+ * L_A may alias K_A. */
+int orc_laplacian(const double *K_A, const double *D, unsigned p, double *L_A, double *alpha);
+
+/* X0: m vectors of length p (column-major: vector j at X + j*p) filled with
+ * U[0,1) from xoshiro256** seeded by splitmix64(seed), vector after vector
+ * (stands in for hpc/inverse_power_it.c:12-47, whose PETSc rand48 stream is
+ * third-party; survey quirk Q7). */
+void orc_random_vectors(double *X, unsigned p, unsigned m, uint64_t seed);
+
+/* hpc/gram_schmidt.c:29-64 classical Gram-Schmidt on m vectors of length n
+ * (column-major). norms (may be NULL) receives the pre-normalisation norms. */
+void orc_orthonormalise(double *X, unsigned n, unsigned m, double *norms);
+/* hpc/gram_schmidt.c:66-77 */
+void orc_normalise(double *X, unsigned n, unsigned m, double *norms);
+
+/* hpc/inverse_power_it.c:49-80: || (I - X X^T) A X ||_F (computed as
+ * A X - X (X^T A X), survey quirk Q5). */
+double orc_residual_norm(const double *A, const double *X, unsigned p, unsigned m);
+
+/* Jacobi-preconditioned CG on m right-hand sides at once, each column stopped
+ * on ||r|| <= rtol ||b|| (stands in for KSPSolve with PETSc's default rtol 1e-5,
+ * hpc/inverse_power_it.c:121-168; survey quirk Q8). B and Xout are column-major
+ * p x m and may alias. Returns the number of block iterations. */
+int orc_block_pcg(const double *A, const double *B, double *Xout, unsigned p, unsigned m,
+                  double rtol, int max_it);
+
+typedef struct orc_eig_stats {
+    int outer_its;
+    int inner_its_total;
+    double residual;
+} orc_eig_stats;
+
+/* hpc/inverse_power_it.c:86-252. A: p*p symmetric row-major. eigvecs: p x m
+ * column-major (normalised PRE-orthogonalisation iterates, :171,:230);
+ * eigvals[m] = 1/norms (:204). X0 is the start block (column-major, not
+ * modified). */
+int orc_inverse_power_iteration(const double *A, unsigned p, unsigned m, const double *X0,
+                                int opti_gs, double epsilon, double inner_rtol, int max_outer,
+                                double *eigvecs, double *eigvals, orc_eig_stats *stats);
+
+/* hpc/nystroem.c:5-69 with L_B = -alpha K_B generated on the fly
+ * (hpc/laplacian.c:37-38): phi (N x m column-major, SAMPLE-FIRST row order)
+ * = [phi_A ; L_B^T (phi_A diag(1/eigvals))]. */
+int orc_nystroem(const orc_params *prm, const uint8_t *img, int width, int height,
+                 unsigned p, const unsigned *idx, double alpha,
+                 const double *phi_A, const double *eigvals, unsigned m, double *phi);
+
+/* hpc/utils.c:134-173: sample-first rows -> raster order. in/out: N x m
+ * column-major. literal != 0 runs the reference's O(N p) scan. */
+int orc_permutation(const double *in, double *out, unsigned N, unsigned m,
+                    const unsigned *idx, unsigned p, int literal);
+
+/* hpc/display.c:58-83 + hpc/utils.c:492-534: z = y + gain * Phi diag(f) Phi^T y,
+ * z > 255 -> 255, then (survey quirk Q4) clamp below at 0 and truncate.
+ * phi: N x m column-major in raster order. zf (may be NULL): z before the
+ * clamp/cast. */
+int orc_result_from_laplacian(const uint8_t *img, int width, int height, const double *phi,
+                              const double *f_eigvals, unsigned m, double gain,
+                              double *zf, uint8_t *out);
+
+/* Whole approximate path (hpc/image_processing.c:183-277 including the
+ * commented tail :240-275). Returns 0 on success. */
+typedef struct orc_run {
+    unsigned p_requested;  /* in */
+    unsigned m;            /* in: number of eigenpairs (>= p realised -> p-1, :96-108) */
+    int opti_gs;           /* in */
+    double epsilon;        /* in */
+    double inner_rtol;     /* in */
+    int max_outer;         /* in */
+    uint64_t seed;         /* in */
+    double gain;           /* in: 3.0 hpc/display.c:73 */
+    unsigned p;            /* out: realised sample count */
+    double alpha;          /* out */
+    orc_eig_stats eig;     /* out */
+    double t_affinity, t_laplacian, t_eigen, t_nystroem, t_filter; /* out, seconds */
+} orc_run;
+
+int orc_image_processing(const orc_params *prm, const uint8_t *img, int width, int height,
+                         orc_run *run, double *eigvals_out /* m or NULL */,
+                         double *zf /* N or NULL */, uint8_t *out /* N */);
+
+/* hpc/image_processing.c:155-181 (-no_approx): z = clamp(y - L y) with the full
+ * N x N Laplacian, never stored (hpc/affinity.c:264-336, hpc/laplacian.c:44-65,
+ * hpc/display.c:128-149). */
+int orc_entire_computation(const orc_params *prm, const uint8_t *img, int width, int height,
+                           double *zf, uint8_t *out);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
