@@ -1,0 +1,227 @@
+// affinity.hip -- bilateral affinity kernels: sample tables, degree (row sums of
+// [K_A K_B] with K_B generated on the fly), K_A / L_A materialisation.
+//
+// Replaces ComputeAffinityMatrices (hpc/affinity.c:129-262) and the row-sum half
+// of ComputeLaplacianMatrix (hpc/laplacian.c:18-29). K_B (p x (N-p)) is never
+// stored: 5.3 TiB at 4096^2 / 0.5 %.
+#include "glf_internal.hpp"
+
+namespace glf {
+
+// ---- sample tables ------------------------------------------------------------------
+
+__global__ void k_sample_tables(const uint8_t *__restrict__ img, int width, int64_t N, unsigned p,
+                                const uint32_t *__restrict__ idx, float4 *__restrict__ samples,
+                                uint8_t *__restrict__ mask)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p) return;
+    const uint32_t px = idx[i];
+    if ((int64_t)px >= N) return; // validated on the host as well
+    // num2x / num2y, hpc/utils.c:11-19: x = row, y = column
+    samples[i] = make_float4((float)(px / (uint32_t)width), (float)(px % (uint32_t)width), (float)img[px], 0.f);
+    mask[px] = 1;
+}
+
+int build_sample_tables(glf_ctx *ctx, const uint8_t *d_img, int width, int height, unsigned p,
+                        const unsigned *h_idx, SampleTables &out)
+{
+    const int64_t N = (int64_t)width * height;
+    if (p == 0 || !h_idx) return set_error(ctx, GLF_ERR_INVALID, "empty sample set");
+    for (unsigned i = 0; i < p; ++i) {
+        if ((int64_t)h_idx[i] >= N || (i && h_idx[i] <= h_idx[i - 1]))
+            return set_error(ctx, GLF_ERR_INVALID, "sample_indices must be ascending and < width*height (i=%u)", i);
+    }
+    GLF_TRY(out.samples.alloc(ctx, p));
+    GLF_TRY(out.mask.alloc(ctx, (size_t)N));
+    GLF_TRY(out.idx.alloc(ctx, p));
+    GLF_HIP(ctx, hipMemcpyAsync(out.idx.p, h_idx, sizeof(uint32_t) * p, hipMemcpyHostToDevice, ctx->stream));
+    GLF_HIP(ctx, hipMemsetAsync(out.mask.p, 0, (size_t)N, ctx->stream));
+    hipLaunchKernelGGL(k_sample_tables, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, d_img, width, N, p,
+                       out.idx.p, out.samples.p, out.mask.p);
+    GLF_LAUNCH_CHECK(ctx);
+    // h_idx is pageable host memory: make sure the async copy has consumed it
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+// ---- degree: D[i] = sum_pixels K(sample i, pixel) --------------------------------------
+//
+// lane = sample (its row/col/value live in VGPRs), loop over pixels whose values
+// are staged per image row in LDS as floats and read back as wave-wide
+// broadcasts (ds_read_b128 = 4 pixels). VALU/transcendental-bound by design:
+// HBM traffic is ~N bytes per sample block. 7 VALU + 1 v_exp_f32 per entry.
+// Accumulation: f32 within one image row, f64 across rows and chunks
+// (fixed order => bitwise reproducible).
+
+constexpr int DEG_THREADS = 256;
+constexpr int DEG_MAXW = 8192; // floats of LDS per staged row segment
+
+__global__ __launch_bounds__(DEG_THREADS) void k_degree(const uint8_t *__restrict__ img, int width, int row0,
+                                                         int row1, int rows_per_chunk,
+                                                         const float4 *__restrict__ samples, unsigned p,
+                                                         float s_loc, float s_val, double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float rowv[DEG_MAXW];
+    const unsigned i = blockIdx.x * DEG_THREADS + threadIdx.x;
+    const bool live = i < p;
+    const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r_begin = row0 + (int)blockIdx.y * rows_per_chunk;
+    const int r_end = min(r_begin + rows_per_chunk, row1);
+    double total = 0.0;
+    for (int r = r_begin; r < r_end; ++r) {
+        const float dr = s.x - (float)r;
+        const float a = dr * dr * s_loc;
+        for (int c0 = 0; c0 < width; c0 += DEG_MAXW) {
+            const int seg = min(DEG_MAXW, width - c0);
+            const int seg4 = (seg + 3) & ~3;
+            __syncthreads(); // previous segment fully consumed
+            for (int c = threadIdx.x; c < seg4; c += DEG_THREADS)
+                // pad with a value that makes the kernel entry exactly 0 only through the
+                // guard below; padded lanes are skipped, the value is irrelevant
+                rowv[c] = (c < seg) ? (float)img[(size_t)r * width + c0 + c] : 0.f;
+            __syncthreads();
+            float acc = 0.f;
+            float dc = s.y - (float)c0; // exact integer, decremented per pixel
+            const int full4 = seg & ~3;
+            for (int c = 0; c < full4; c += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&rowv[c]);
+                {
+                    const float dv = s.z - v.x;
+                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                    acc += __builtin_amdgcn_exp2f(-t);
+                    dc -= 1.f;
+                }
+                {
+                    const float dv = s.z - v.y;
+                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                    acc += __builtin_amdgcn_exp2f(-t);
+                    dc -= 1.f;
+                }
+                {
+                    const float dv = s.z - v.z;
+                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                    acc += __builtin_amdgcn_exp2f(-t);
+                    dc -= 1.f;
+                }
+                {
+                    const float dv = s.z - v.w;
+                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                    acc += __builtin_amdgcn_exp2f(-t);
+                    dc -= 1.f;
+                }
+            }
+            for (int c = full4; c < seg; ++c) {
+                const float dv = s.z - rowv[c];
+                const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                acc += __builtin_amdgcn_exp2f(-t);
+                dc -= 1.f;
+            }
+            total += (double)acc;
+        }
+    }
+    if (live) partial[(size_t)blockIdx.y * p + i] = total;
+}
+
+__global__ void k_reduce_partials(const double *__restrict__ partial, unsigned p, int nchunks,
+                                  double *__restrict__ out)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * p + i];
+    out[i] = s;
+}
+
+int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
+                const float4 *d_samples, unsigned p, KernelCoef coef, double *d_degree)
+{
+    if (row0 < 0 || row1 > height || row0 > row1) return set_error(ctx, GLF_ERR_INVALID, "bad row range");
+    if (row0 == row1) {
+        GLF_HIP(ctx, hipMemsetAsync(d_degree, 0, sizeof(double) * p, ctx->stream));
+        return GLF_OK;
+    }
+    const int nsb = (int)ceil_div(p, DEG_THREADS);
+    const int rows = row1 - row0;
+    // enough workgroups to fill 256 CUs several times over, at most 16 rows per chunk
+    int rows_per_chunk = (int)((int64_t)rows * nsb / 4096);
+    if (rows_per_chunk < 1) rows_per_chunk = 1;
+    if (rows_per_chunk > 16) rows_per_chunk = 16;
+    int nchunks = (int)ceil_div(rows, rows_per_chunk);
+    if (nchunks > 65535) {
+        rows_per_chunk = (int)ceil_div(rows, 65535);
+        nchunks = (int)ceil_div(rows, rows_per_chunk);
+    }
+    DevBuf<double> partial;
+    GLF_TRY(partial.alloc(ctx, (size_t)nchunks * p));
+    hipLaunchKernelGGL(k_degree, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, ctx->stream, d_img, width, row0, row1,
+                       rows_per_chunk, d_samples, p, coef.s_loc, coef.s_val, partial.p);
+    GLF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks,
+                       d_degree);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream)); // partial is freed at scope exit
+    return GLF_OK;
+}
+
+// ---- K_A / L_A (p x p) -----------------------------------------------------------------
+//
+// out[i][j] = scale * K(sample i, sample j); Laplacian form (hpc/laplacian.c:31-35):
+// L_A = alpha * (diag(D) - K_A)  => off-diagonal -alpha*K, diagonal alpha*(D_i - K_ii).
+// Write-bound: 4 p^2 bytes (29 GB at p = 85 264).
+
+__global__ __launch_bounds__(256) void k_sample_matrix(const float4 *__restrict__ samples, unsigned p, float s_loc,
+                                                        float s_val, float *__restrict__ out, int64_t ld,
+                                                        int laplacian, double alpha,
+                                                        const double *__restrict__ degree)
+{
+    const unsigned j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const unsigned i0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+    if (j >= p) return;
+    const float4 sj = samples[j];
+    const float fscale = laplacian ? (float)(-alpha) : 1.0f;
+#pragma unroll 4
+    for (unsigned ii = 0; ii < 16; ++ii) {
+        const unsigned i = i0 + ii;
+        if (i >= p) break;
+        const float4 si = samples[i]; // wave-uniform -> scalar load
+        float k = kernel_eval(si.x - sj.x, si.y - sj.y, si.z - sj.z, s_loc, s_val);
+        float v = fscale * k;
+        if (laplacian && i == j) v = (float)(alpha * (degree[i] - (double)k));
+        out[(size_t)i * ld + j] = v;
+    }
+}
+
+int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef, float *d_out,
+                        int64_t ld, bool laplacian, double alpha, const double *d_degree)
+{
+    dim3 grid((p + 63) / 64, (p + 63) / 64);
+    hipLaunchKernelGGL(k_sample_matrix, grid, dim3(256), 0, ctx->stream, d_samples, p, coef.s_loc, coef.s_val, d_out,
+                       ld, laplacian ? 1 : 0, alpha, d_degree);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+__global__ __launch_bounds__(256) void k_laplacian_from_KA(const float *__restrict__ KA, int64_t ldk, unsigned p,
+                                                            float *__restrict__ LA, int64_t ld, double alpha,
+                                                            const double *__restrict__ degree)
+{
+    const unsigned j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    for (unsigned i = blockIdx.y; i < p; i += gridDim.y) {
+        const float k = KA[(size_t)i * ldk + j];
+        // MatAYPX(L_A, -1, D_A) then MatScale(alpha), hpc/laplacian.c:33-35
+        LA[(size_t)i * ld + j] = (i == j) ? (float)(alpha * (degree[i] - (double)k)) : (float)(-alpha) * k;
+    }
+}
+
+int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, float *d_LA, int64_t ld,
+                      double alpha, const double *d_degree)
+{
+    hipLaunchKernelGGL(k_laplacian_from_KA, dim3((p + 255) / 256, p < 16384 ? p : 16384), dim3(256), 0, ctx->stream, d_KA, ldk, p, d_LA,
+                       ld, alpha, d_degree);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+} // namespace glf

@@ -1,0 +1,236 @@
+// ctx.hip -- context, flat device buffers and matrix descriptors of the C-ABI (include/glf.h).
+#include "glf_internal.hpp"
+
+#include <cmath>
+#include <cstdlib>
+
+extern "C" {
+
+const char *glf_strerror(int status)
+{
+    switch (status) {
+    case GLF_OK: return "ok";
+    case GLF_ERR_INVALID: return "invalid argument";
+    case GLF_ERR_NOMEM: return "out of memory";
+    case GLF_ERR_HIP: return "HIP runtime error";
+    case GLF_ERR_NODEVICE: return "no usable gfx950 device";
+    case GLF_ERR_COMM: return "collective callback failed";
+    case GLF_ERR_NOCONV: return "eigensolver did not converge";
+    case GLF_ERR_IO: return "image I/O error";
+    case GLF_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+int glf_ctx_create(glf_ctx **out, int device, void *hip_stream)
+{
+    if (!out) return GLF_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GLF_ERR_NODEVICE;
+    if (device < 0 || device >= ndev) return GLF_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return GLF_ERR_NODEVICE;
+    glf_ctx *ctx = new (std::nothrow) glf_ctx();
+    if (!ctx) return GLF_ERR_NOMEM;
+    ctx->device = device;
+    if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
+        delete ctx;
+        return GLF_ERR_NODEVICE;
+    }
+    // The kernels are compiled for gfx950 only (MFMA f32 32x32x2, wave64): fail
+    // loudly on anything else instead of letting a launch die later.
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "glf: device %d is %s, this library is built for gfx950 only\n", device,
+                ctx->prop.gcnArchName);
+        delete ctx;
+        return GLF_ERR_NODEVICE;
+    }
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        ctx->owns_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return GLF_ERR_HIP;
+        }
+        ctx->owns_stream = true;
+    }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return GLF_ERR_HIP;
+        }
+    ctx->comm.rank = 0;
+    ctx->comm.size = 1;
+    *out = ctx;
+    return GLF_OK;
+}
+
+int glf_ctx_destroy(glf_ctx *ctx)
+{
+    if (!ctx) return GLF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GLF_OK;
+}
+
+int glf_ctx_synchronize(glf_ctx *ctx)
+{
+    if (!ctx) return GLF_ERR_INVALID;
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+const char *glf_ctx_last_error(const glf_ctx *ctx) { return ctx ? ctx->last_error : "null context"; }
+
+int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *num_cus, size_t *total_mem)
+{
+    if (!ctx) return GLF_ERR_INVALID;
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (num_cus) *num_cus = ctx->prop.multiProcessorCount;
+    if (total_mem) *total_mem = ctx->prop.totalGlobalMem;
+    return GLF_OK;
+}
+
+int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm)
+{
+    if (!ctx) return GLF_ERR_INVALID;
+    if (!comm || comm->size <= 1) {
+        ctx->comm = glf_comm{};
+        ctx->comm.size = 1;
+        ctx->has_comm = false;
+        return GLF_OK;
+    }
+    if (comm->rank < 0 || comm->rank >= comm->size || !comm->allreduce_sum_f64 || !comm->allreduce_sum_f32)
+        return glf::set_error(ctx, GLF_ERR_INVALID, "glf_comm needs rank < size and both allreduce callbacks");
+    ctx->comm = *comm;
+    ctx->has_comm = true;
+    return GLF_OK;
+}
+
+int glf_malloc(glf_ctx *ctx, void **dptr, size_t bytes)
+{
+    if (!ctx || !dptr) return GLF_ERR_INVALID;
+    *dptr = nullptr;
+    if (bytes == 0) return GLF_OK;
+    GLF_HIP(ctx, hipSetDevice(ctx->device));
+    GLF_HIP(ctx, hipMalloc(dptr, bytes));
+    return GLF_OK;
+}
+
+int glf_free(glf_ctx *ctx, void *dptr)
+{
+    if (!ctx) return GLF_ERR_INVALID;
+    if (dptr) GLF_HIP(ctx, hipFree(dptr));
+    return GLF_OK;
+}
+
+int glf_memcpy_h2d(glf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return GLF_ERR_INVALID;
+    GLF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+int glf_memcpy_d2h(glf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return GLF_ERR_INVALID;
+    GLF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+int glf_memset(glf_ctx *ctx, void *dst, int value, size_t bytes)
+{
+    if (!ctx || (bytes && !dst)) return GLF_ERR_INVALID;
+    GLF_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return GLF_OK;
+}
+
+int glf_mat_create_dense(glf_ctx *ctx, glf_mat *mat, int64_t rows, int64_t cols, int64_t ld)
+{
+    if (!ctx || !mat || rows < 0 || cols < 0) return GLF_ERR_INVALID;
+    if (ld <= 0) ld = cols;
+    if (ld < cols) return GLF_ERR_INVALID;
+    std::memset(mat, 0, sizeof(*mat));
+    mat->kind = GLF_MAT_DENSE;
+    mat->rows = rows;
+    mat->cols = cols;
+    mat->ld = ld;
+    void *d = nullptr;
+    GLF_TRY(glf_malloc(ctx, &d, sizeof(float) * (size_t)rows * (size_t)ld));
+    mat->data = static_cast<float *>(d);
+    mat->owns_data = 1;
+    if (d) GLF_HIP(ctx, hipMemsetAsync(d, 0, sizeof(float) * (size_t)rows * (size_t)ld, ctx->stream));
+    return GLF_OK;
+}
+
+int glf_mat_create_diag(glf_ctx *ctx, glf_mat *mat, int64_t n)
+{
+    if (!ctx || !mat || n < 0) return GLF_ERR_INVALID;
+    std::memset(mat, 0, sizeof(*mat));
+    mat->kind = GLF_MAT_DIAG;
+    mat->rows = mat->cols = n;
+    mat->ld = 1;
+    void *d = nullptr;
+    GLF_TRY(glf_malloc(ctx, &d, sizeof(float) * (size_t)n));
+    mat->data = static_cast<float *>(d);
+    mat->owns_data = 1;
+    return GLF_OK;
+}
+
+int glf_mat_destroy(glf_ctx *ctx, glf_mat *mat)
+{
+    if (!ctx || !mat) return GLF_ERR_INVALID;
+    if (mat->owns_data && mat->data) (void)hipFree(mat->data);
+    if (mat->owns_desc) {
+        if (mat->samples) (void)hipFree(const_cast<float *>(mat->samples));
+        if (mat->mask) (void)hipFree(const_cast<uint8_t *>(mat->mask));
+        if (mat->idx) (void)hipFree(const_cast<uint32_t *>(mat->idx));
+        if (mat->degree) (void)hipFree(mat->degree);
+    }
+    std::memset(mat, 0, sizeof(*mat));
+    return GLF_OK;
+}
+
+void glf_options_default(glf_options *opt)
+{
+    if (!opt) return;
+    std::memset(opt, 0, sizeof(*opt));
+    opt->struct_size = sizeof(glf_options);
+    opt->num_samples = 0;
+    opt->sample_frac = 0.01;   // hpc/image_processing.c:187
+    opt->num_eigvals = 0;      // -> p - 1, :96-108
+    opt->opti_gs = 1;          // :128-140
+    opt->epsilon = 0.1;        // :151
+    opt->inner_rtol = 1e-5;    // PETSc KSP default rtol
+    opt->max_outer = 100000;
+    opt->seed = 1;
+    opt->gain = 3.0f;          // hpc/display.c:73
+    opt->h_loc = 40.0f;        // hpc/affinity.c:118
+    opt->h_val = 30.0f;        // hpc/affinity.c:117
+    opt->kernel = GLF_KERNEL_BILATERAL;
+    opt->filter_pow = 1;       // MatPow no-op, hpc/utils.c:721
+}
+
+void glf_host_free(void *ptr) { std::free(ptr); }
+
+} // extern "C"
+
+namespace glf {
+
+KernelCoef make_coef(int kernel, float h_loc, float h_val)
+{
+    const double log2e = 1.4426950408889634;
+    KernelCoef c;
+    c.s_loc = (kernel == GLF_KERNEL_PHOTOMETRIC) ? 0.0f : (float)(log2e / ((double)h_loc * (double)h_loc));
+    c.s_val = (kernel == GLF_KERNEL_SPATIAL) ? 0.0f : (float)(log2e / ((double)h_val * (double)h_val));
+    return c;
+}
+
+} // namespace glf

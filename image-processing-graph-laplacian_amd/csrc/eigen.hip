@@ -1,0 +1,771 @@
+// eigen.hip -- inverse subspace iteration on L_A (hpc/inverse_power_it.c:86-252) with
+// classical Gram-Schmidt (hpc/gram_schmidt.c:29-64), on flat device buffers.
+//
+// Layout: A = L_A is p x p row-major with lda >= round_up(p,32), lda % 4 == 0 and
+// ZERO padding columns. Vector blocks (X, P, R, AP ...) are [p32][ld] row-major,
+// p32 = round_up(p,32), ld = m rounded up to 32; padding rows/columns are zero
+// and never written. One "Vec" of the reference = one column here.
+//
+// Kernels:
+//   k_block_matvec   Y = A X      f32 MFMA 32x32x2, A streamed once from HBM (HBM/MFMA bound)
+//   k_gram           G = X^T Y    f32 MFMA, split over row chunks
+//   k_cg_*           Jacobi-PCG vector updates with per-column scalars (HBM bound, tiny)
+//   k_gs_*           classical Gram-Schmidt column sweeps
+// All reductions go through fixed-order f64 partial buffers => reproducible.
+#include "glf_internal.hpp"
+
+#include <cmath>
+
+namespace glf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =====================================================================================
+// Y[p32][ld] = A[p][lda] * X[p32][ld]
+// =====================================================================================
+// Workgroup = 4 waves x 32 rows. Each lane loads 16 consecutive floats of ITS row per
+// 32-wide K tile (lanes 0-31: k 0..15, lanes 32-63: k 16..31), which are directly
+// the A operands of 16 v_mfma_f32_32x32x2_f32 (lane l supplies A[i=l&31][k=l>>5]):
+// MFMA t pairs k = kb+t (lower half) with k = kb+16+t (upper half); the B operand
+// X[k][j] is read from an LDS copy of the X tile with the same pairing. No LDS
+// round trip for A, one 128-B line per row per tile.
+
+template <int MB> // MB = ld / 32 column blocks
+__global__ __launch_bounds__(256) void k_block_matvec(const float *__restrict__ A, int64_t lda, unsigned p,
+                                                       unsigned p32, const float *__restrict__ X,
+                                                       float *__restrict__ Y)
+{
+    constexpr int LD = MB * 32;
+    __shared__ __attribute__((aligned(16))) float xs[2][32 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned row = blockIdx.x * 128 + wave * 32 + l31;
+    const unsigned rowc = row < p ? row : p - 1; // clamp loads, skip the store
+    const float *arow = A + (size_t)rowc * lda + 16 * half;
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    const int ntiles = p32 / 32;
+    // stage X tile 0
+    for (int e = threadIdx.x * 4; e < 32 * LD; e += 256 * 4)
+        *reinterpret_cast<float4 *>(&xs[0][e]) = *reinterpret_cast<const float4 *>(&X[e]);
+    float4 a_cur[4], a_nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_cur[q] = *reinterpret_cast<const float4 *>(arow + 4 * q);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) {
+            const float *xn = X + (size_t)(t + 1) * 32 * LD;
+            for (int e = threadIdx.x * 4; e < 32 * LD; e += 256 * 4)
+                *reinterpret_cast<float4 *>(&xs[buf ^ 1][e]) = *reinterpret_cast<const float4 *>(&xn[e]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                a_nxt[q] = *reinterpret_cast<const float4 *>(arow + (size_t)(t + 1) * 32 + 4 * q);
+        }
+        const float *xb = &xs[buf][(16 * half) * LD + l31];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av[4] = {a_cur[q].x, a_cur[q].y, a_cur[q].z, a_cur[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 4 * q + e;
+#pragma unroll
+                for (int b = 0; b < MB; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xb[kk * LD + 32 * b], acc[b], 0, 0, 0);
+            }
+        }
+        __syncthreads(); // xs[buf] consumed by all waves, xs[buf^1] fully written
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    }
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const unsigned rbase = blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (orow < p) Y[(size_t)orow * LD + 32 * b + l31] = acc[b][r];
+        }
+}
+
+int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld)
+{
+    const unsigned p32 = (unsigned)round_up(p, 32);
+    if (lda < (int64_t)p32 || (lda & 3) || !valid_ld(ld))
+        return set_error(ctx, GLF_ERR_INVALID, "block_matvec: lda=%lld ld=%u (need lda >= round_up(p,32), lda%%4==0, ld%%32==0, ld<=256)",
+                         (long long)lda, ld);
+    if (reinterpret_cast<uintptr_t>(A) & 15)
+        return set_error(ctx, GLF_ERR_INVALID, "block_matvec: A must be 16-byte aligned");
+    dim3 grid((unsigned)ceil_div(p, 128)), block(256);
+    switch (ld / 32) {
+    case 1: hipLaunchKernelGGL(k_block_matvec<1>, grid, block, 0, ctx->stream, A, lda, p, p32, X, Y); break;
+    case 2: hipLaunchKernelGGL(k_block_matvec<2>, grid, block, 0, ctx->stream, A, lda, p, p32, X, Y); break;
+    case 4: hipLaunchKernelGGL(k_block_matvec<4>, grid, block, 0, ctx->stream, A, lda, p, p32, X, Y); break;
+    case 8: hipLaunchKernelGGL(k_block_matvec<8>, grid, block, 0, ctx->stream, A, lda, p, p32, X, Y); break;
+    default: return set_error(ctx, GLF_ERR_UNSUPPORTED, "ld %u (must be 32, 64, 128 or 256)", ld);
+    }
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+// =====================================================================================
+// Small helpers: fixed-order sums of per-block partials
+// =====================================================================================
+
+constexpr int RED_ROWS = 512; // rows per reduction workgroup
+
+// out[c] = sum_blk partial[blk][c], c < ncols
+__global__ void k_sum_partials(const double *__restrict__ partial, int nblk, int ncols, double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * ncols + c];
+    out[c] = s;
+}
+
+// Block-level column reduction helper: 256 threads, column = t % ld, row lane = t / ld.
+// val[v] are this thread's partial sums; result (summed over the row lanes) is written
+// to partial[(blockIdx.x * NV + v) * ld + col].
+template <int NV>
+__device__ __forceinline__ void block_col_reduce(double (&val)[NV], unsigned ld, double *__restrict__ partial,
+                                                 double *sh /* [NV][256] */)
+{
+    const int t = threadIdx.x;
+    const int col = t % ld, nrl = 256 / ld;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sh[v * 256 + t] = val[v];
+    __syncthreads();
+    if (t < (int)ld) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double s = 0.0;
+            for (int r = 0; r < nrl; ++r) s += sh[v * 256 + r * ld + col];
+            partial[((size_t)blockIdx.x * NV + v) * ld + col] = s;
+        }
+    }
+}
+
+// =====================================================================================
+// Jacobi-PCG on all columns at once (stands in for KSPSolve x m, hpc/inverse_power_it.c:165-168)
+// =====================================================================================
+
+struct CgScalars {    // device, per column (ld entries each)
+    double *rz;       // r . z
+    double *bn2;      // ||b||^2
+    double *alpha;
+    double *beta;
+    int *active;      // 1 while the column still iterates
+    int *nactive;     // single int
+};
+
+// init: R = B (B lives in XB), X = 0 (XB is overwritten at the end), P = dinv .* R
+__global__ __launch_bounds__(256) void k_cg_init(const float *__restrict__ B, const float *__restrict__ dinv,
+                                                  float *__restrict__ R, float *__restrict__ P,
+                                                  float *__restrict__ Xs, unsigned p, unsigned ld,
+                                                  double *__restrict__ partial)
+{
+    __shared__ double sh[2 * 256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    double v[2] = {0.0, 0.0};
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned r = rl; r < RED_ROWS; r += nrl) {
+        const unsigned i = base + r;
+        if (i >= p) break;
+        const size_t o = (size_t)i * ld + col;
+        const float b = B[o], d = dinv[i];
+        const float z = d * b;
+        R[o] = b;
+        P[o] = z;
+        Xs[o] = 0.f;
+        v[0] += (double)b * (double)z; // r.z
+        v[1] += (double)b * (double)b; // ||b||^2
+    }
+    block_col_reduce<2>(v, ld, partial, sh);
+}
+
+__global__ void k_cg_init_scalars(const double *__restrict__ partial, int nblk, unsigned ld, unsigned m, CgScalars s)
+{
+    const int c = threadIdx.x;
+    if (c < (int)ld) {
+        double rz = 0.0, bn2 = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            rz += partial[((size_t)b * 2 + 0) * ld + c];
+            bn2 += partial[((size_t)b * 2 + 1) * ld + c];
+        }
+        s.rz[c] = rz;
+        s.bn2[c] = bn2;
+        s.active[c] = (c < (int)m && bn2 > 0.0) ? 1 : 0;
+        s.alpha[c] = 0.0;
+        s.beta[c] = 0.0;
+    }
+    __syncthreads();
+    if (c == 0) {
+        int n = 0;
+        for (unsigned k = 0; k < ld; ++k) n += s.active[k];
+        *s.nactive = n;
+    }
+}
+
+// partial p.Ap
+__global__ __launch_bounds__(256) void k_cg_dot(const float *__restrict__ P, const float *__restrict__ AP, unsigned p,
+                                                 unsigned ld, double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    double v[1] = {0.0};
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned r = rl; r < RED_ROWS; r += nrl) {
+        const unsigned i = base + r;
+        if (i >= p) break;
+        const size_t o = (size_t)i * ld + col;
+        v[0] += (double)P[o] * (double)AP[o];
+    }
+    block_col_reduce<1>(v, ld, partial, sh);
+}
+
+__global__ void k_cg_alpha(const double *__restrict__ partial, int nblk, unsigned ld, CgScalars s)
+{
+    const int c = threadIdx.x;
+    if (c >= (int)ld) return;
+    double pap = 0.0;
+    for (int b = 0; b < nblk; ++b) pap += partial[(size_t)b * ld + c];
+    s.alpha[c] = s.active[c] ? s.rz[c] / pap : 0.0;
+}
+
+// x += alpha p ; r -= alpha Ap ; partial ||r||^2 and r.(dinv r)
+__global__ __launch_bounds__(256) void k_cg_update(float *__restrict__ Xs, float *__restrict__ R,
+                                                    const float *__restrict__ P, const float *__restrict__ AP,
+                                                    const float *__restrict__ dinv, unsigned p, unsigned ld,
+                                                    CgScalars s, double *__restrict__ partial)
+{
+    __shared__ double sh[2 * 256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    const bool act = s.active[col] != 0;
+    const float alpha = (float)s.alpha[col];
+    double v[2] = {0.0, 0.0};
+    const unsigned base = blockIdx.x * RED_ROWS;
+    if (act) {
+        for (unsigned r = rl; r < RED_ROWS; r += nrl) {
+            const unsigned i = base + r;
+            if (i >= p) break;
+            const size_t o = (size_t)i * ld + col;
+            Xs[o] = fmaf(alpha, P[o], Xs[o]);
+            const float rn = fmaf(-alpha, AP[o], R[o]);
+            R[o] = rn;
+            v[0] += (double)rn * (double)rn;
+            v[1] += (double)rn * (double)(dinv[i] * rn);
+        }
+    }
+    block_col_reduce<2>(v, ld, partial, sh);
+}
+
+__global__ void k_cg_beta(const double *__restrict__ partial, int nblk, unsigned ld, double rtol2, CgScalars s)
+{
+    const int c = threadIdx.x;
+    if (c < (int)ld && s.active[c]) {
+        double rr = 0.0, rz = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            rr += partial[((size_t)b * 2 + 0) * ld + c];
+            rz += partial[((size_t)b * 2 + 1) * ld + c];
+        }
+        if (rr <= rtol2 * s.bn2[c]) { // ||r|| <= rtol ||b||
+            s.active[c] = 0;
+            s.beta[c] = 0.0;
+        } else {
+            s.beta[c] = rz / s.rz[c];
+            s.rz[c] = rz;
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+        int n = 0;
+        for (unsigned k = 0; k < ld; ++k) n += s.active[k];
+        *s.nactive = n;
+    }
+}
+
+// p = dinv r + beta p
+__global__ __launch_bounds__(256) void k_cg_pupdate(float *__restrict__ P, const float *__restrict__ R,
+                                                     const float *__restrict__ dinv, unsigned p, unsigned ld,
+                                                     CgScalars s)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned i = (unsigned)(e / ld), col = (unsigned)(e % ld);
+    if (i >= p || !s.active[col]) return;
+    P[e] = fmaf((float)s.beta[col], P[e], dinv[i] * R[e]);
+}
+
+__global__ void k_diag_inv(const float *__restrict__ A, int64_t lda, unsigned p, float *__restrict__ dinv)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p) dinv[i] = 1.0f / A[(size_t)i * lda + i];
+}
+
+struct CgWork {
+    DevBuf<float> R, P, AP, Xs, dinv;
+    DevBuf<double> partial, scal;
+    DevBuf<int> flags;
+    CgScalars s{};
+    int nblk = 0;
+    int *h_nactive = nullptr; // pinned
+    ~CgWork()
+    {
+        if (h_nactive) (void)hipHostFree(h_nactive);
+    }
+    int init(glf_ctx *ctx, unsigned p, unsigned ld)
+    {
+        const size_t n = (size_t)round_up(p, 32) * ld;
+        GLF_TRY(R.alloc(ctx, n));
+        GLF_TRY(P.alloc(ctx, n));
+        GLF_TRY(AP.alloc(ctx, n));
+        GLF_TRY(Xs.alloc(ctx, n));
+        GLF_TRY(dinv.alloc(ctx, p));
+        nblk = (int)ceil_div(p, RED_ROWS);
+        GLF_TRY(partial.alloc(ctx, (size_t)nblk * 2 * ld));
+        GLF_TRY(scal.alloc(ctx, (size_t)4 * ld));
+        GLF_TRY(flags.alloc(ctx, ld + 1));
+        for (float *q : {R.p, P.p, AP.p, Xs.p}) GLF_HIP(ctx, hipMemsetAsync(q, 0, n * sizeof(float), ctx->stream));
+        s.rz = scal.p;
+        s.bn2 = scal.p + ld;
+        s.alpha = scal.p + 2 * ld;
+        s.beta = scal.p + 3 * ld;
+        s.active = flags.p;
+        s.nactive = flags.p + ld;
+        GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_nactive), sizeof(int), hipHostMallocDefault));
+        return GLF_OK;
+    }
+};
+
+static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, unsigned p, float *XB, unsigned m,
+                          unsigned ld, double rtol, int max_it, int *iters)
+{
+    const unsigned p32 = (unsigned)round_up(p, 32);
+    const int nblk = w.nblk;
+    const unsigned nelem_blocks = (unsigned)ceil_div((int64_t)p * ld, 256);
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_cg_init, dim3(nblk), dim3(256), 0, st, XB, w.dinv.p, w.R.p, w.P.p, w.Xs.p, p, ld, w.partial.p);
+    hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, m, w.s);
+    GLF_LAUNCH_CHECK(ctx);
+    int it = 0;
+    GLF_HIP(ctx, hipMemcpyAsync(w.h_nactive, w.s.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    while (*w.h_nactive > 0 && it < max_it) {
+        ++it;
+        GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld));
+        hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p, w.AP.p, p, ld, w.partial.p);
+        hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.s);
+        hipLaunchKernelGGL(k_cg_update, dim3(nblk), dim3(256), 0, st, w.Xs.p, w.R.p, w.P.p, w.AP.p, w.dinv.p, p, ld, w.s,
+                           w.partial.p);
+        hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, rtol * rtol, w.s);
+        hipLaunchKernelGGL(k_cg_pupdate, dim3(nelem_blocks), dim3(256), 0, st, w.P.p, w.R.p, w.dinv.p, p, ld, w.s);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_HIP(ctx, hipMemcpyAsync(w.h_nactive, w.s.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+    }
+    (void)p32;
+    GLF_HIP(ctx, hipMemcpyAsync(XB, w.Xs.p, sizeof(float) * (size_t)p * ld, hipMemcpyDeviceToDevice, st));
+    if (iters) *iters = it;
+    return (*w.h_nactive > 0) ? set_error(ctx, GLF_ERR_NOCONV, "block PCG: %d columns unconverged after %d iterations",
+                                          *w.h_nactive, it)
+                              : GLF_OK;
+}
+
+int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, unsigned m, unsigned ld, double rtol,
+              int max_it, int *iters)
+{
+    CgWork w;
+    GLF_TRY(w.init(ctx, p, ld));
+    hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, A, lda, p, w.dinv.p);
+    GLF_LAUNCH_CHECK(ctx);
+    int rc = block_pcg_work(ctx, w, A, lda, p, XB, m, ld, rtol, max_it, iters);
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+// =====================================================================================
+// Classical Gram-Schmidt (hpc/gram_schmidt.c:29-64), column k at a time
+// =====================================================================================
+
+// partial[blk][0][j] = sum_i X[i][k] X[i][j], partial[blk][1][j] = sum_i X[i][j]^2   (j < k; j == k gives ||x_k||^2)
+__global__ __launch_bounds__(256) void k_gs_dots(const float *__restrict__ X, unsigned n, unsigned ld, unsigned k,
+                                                  double *__restrict__ partial)
+{
+    __shared__ double sh[2 * 256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    double v[2] = {0.0, 0.0};
+    const unsigned base = blockIdx.x * RED_ROWS;
+    if (col <= (int)k) {
+        for (unsigned r = rl; r < RED_ROWS; r += nrl) {
+            const unsigned i = base + r;
+            if (i >= n) break;
+            const float xj = X[(size_t)i * ld + col], xk = X[(size_t)i * ld + k];
+            v[0] += (double)xk * (double)xj;
+            v[1] += (double)xj * (double)xj;
+        }
+    }
+    block_col_reduce<2>(v, ld, partial, sh);
+}
+
+// coef[j] = <x_k, u_j> / <u_j, u_j>  (Projection, hpc/gram_schmidt.c:11-21)
+__global__ void k_gs_coef(const double *__restrict__ partial, int nblk, unsigned ld, unsigned k, float *__restrict__ coef)
+{
+    const int c = threadIdx.x;
+    if (c >= (int)ld) return;
+    double d = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        d += partial[((size_t)b * 2 + 0) * ld + c];
+        q += partial[((size_t)b * 2 + 1) * ld + c];
+    }
+    coef[c] = (c < (int)k && q != 0.0) ? (float)(d / q) : 0.f;
+}
+
+// x_k <- x_k - sum_{j<k} coef[j] u_j (VecAXPBY :53); partial ||x_k||^2. One wave per row group.
+__global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned k,
+                                                   const float *__restrict__ coef, double *__restrict__ partial)
+{
+    __shared__ double shn[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double nrm = 0.0;
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned r = wave; r < RED_ROWS; r += 4) {
+        const unsigned i = base + r;
+        if (i >= n) break;
+        float s = 0.f;
+        for (unsigned j = lane; j < k; j += 64) s = fmaf(coef[j], X[(size_t)i * ld + j], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            const float xn = X[(size_t)i * ld + k] - s;
+            X[(size_t)i * ld + k] = xn;
+            nrm += (double)xn * (double)xn;
+        }
+    }
+    if (lane == 0) shn[wave] = nrm;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = shn[0] + shn[1] + shn[2] + shn[3];
+}
+
+// norm[k] = sqrt(sum partial); scale column k by 1/norm (VecNormalize :59)
+__global__ void k_gs_norm(const double *__restrict__ partial, int nblk, unsigned k, double *__restrict__ norms)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += partial[b];
+        norms[k] = sqrt(s);
+    }
+}
+
+__global__ void k_scale_col(float *__restrict__ X, unsigned n, unsigned ld, unsigned k, const double *__restrict__ norms)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double nr = norms[k];
+    if (nr != 0.0) X[(size_t)i * ld + k] = (float)((double)X[(size_t)i * ld + k] / nr);
+}
+
+// column norms only (NormaliseVecs, hpc/gram_schmidt.c:66-77)
+__global__ __launch_bounds__(256) void k_col_sumsq(const float *__restrict__ X, unsigned n, unsigned ld,
+                                                    double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    double v[1] = {0.0};
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned r = rl; r < RED_ROWS; r += nrl) {
+        const unsigned i = base + r;
+        if (i >= n) break;
+        const float x = X[(size_t)i * ld + col];
+        v[0] += (double)x * (double)x;
+    }
+    block_col_reduce<1>(v, ld, partial, sh);
+}
+
+__global__ void k_norms_from_partials(const double *__restrict__ partial, int nblk, unsigned ld, double *__restrict__ norms)
+{
+    const int c = threadIdx.x;
+    if (c >= (int)ld) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * ld + c];
+    norms[c] = sqrt(s);
+}
+
+__global__ void k_scale_all(float *__restrict__ X, unsigned n, unsigned ld, unsigned m, const double *__restrict__ norms)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned i = (unsigned)(e / ld), c = (unsigned)(e % ld);
+    if (i >= n || c >= m) return;
+    const double nr = norms[c];
+    if (nr != 0.0) X[e] = (float)((double)X[e] / nr);
+}
+
+static int orthonormalise_dev(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *d_partial,
+                              float *d_coef, double *d_norms)
+{
+    const int nblk = (int)ceil_div(n, RED_ROWS);
+    hipStream_t st = ctx->stream;
+    for (unsigned k = 0; k < m; ++k) {
+        if (k > 0) {
+            hipLaunchKernelGGL(k_gs_dots, dim3(nblk), dim3(256), 0, st, X, n, ld, k, d_partial);
+            hipLaunchKernelGGL(k_gs_coef, dim3(1), dim3(256), 0, st, d_partial, nblk, ld, k, d_coef);
+        }
+        hipLaunchKernelGGL(k_gs_apply, dim3(nblk), dim3(256), 0, st, X, n, ld, k, d_coef, d_partial);
+        hipLaunchKernelGGL(k_gs_norm, dim3(1), dim3(64), 0, st, d_partial, nblk, k, d_norms);
+        hipLaunchKernelGGL(k_scale_col, dim3((n + 255) / 256), dim3(256), 0, st, X, n, ld, k, d_norms);
+    }
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+struct GsWork {
+    DevBuf<double> partial, norms;
+    DevBuf<float> coef;
+    int init(glf_ctx *ctx, unsigned n, unsigned ld)
+    {
+        const int nblk = (int)ceil_div(n, RED_ROWS);
+        GLF_TRY(partial.alloc(ctx, (size_t)nblk * 2 * ld));
+        GLF_TRY(norms.alloc(ctx, ld));
+        GLF_TRY(coef.alloc(ctx, ld));
+        GLF_HIP(ctx, hipMemsetAsync(coef.p, 0, sizeof(float) * ld, ctx->stream));
+        GLF_HIP(ctx, hipMemsetAsync(norms.p, 0, sizeof(double) * ld, ctx->stream));
+        return GLF_OK;
+    }
+};
+
+int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms)
+{
+    if (!valid_ld(ld) || m > ld) return set_error(ctx, GLF_ERR_INVALID, "orthonormalise: ld=%u m=%u", ld, m);
+    GsWork w;
+    GLF_TRY(w.init(ctx, n, ld));
+    GLF_TRY(orthonormalise_dev(ctx, X, n, m, ld, w.partial.p, w.coef.p, w.norms.p));
+    if (h_norms) GLF_HIP(ctx, hipMemcpyAsync(h_norms, w.norms.p, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+static int normalise_dev(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *d_partial, double *d_norms)
+{
+    const int nblk = (int)ceil_div(n, RED_ROWS);
+    hipLaunchKernelGGL(k_col_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, X, n, ld, d_partial);
+    hipLaunchKernelGGL(k_norms_from_partials, dim3(1), dim3(256), 0, ctx->stream, d_partial, nblk, ld, d_norms);
+    hipLaunchKernelGGL(k_scale_all, dim3((unsigned)ceil_div((int64_t)n * ld, 256)), dim3(256), 0, ctx->stream, X, n, ld, m,
+                       d_norms);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms)
+{
+    if (!valid_ld(ld) || m > ld) return set_error(ctx, GLF_ERR_INVALID, "normalise: ld=%u m=%u", ld, m);
+    GsWork w;
+    GLF_TRY(w.init(ctx, n, ld));
+    GLF_TRY(normalise_dev(ctx, X, n, m, ld, w.partial.p, w.norms.p));
+    if (h_norms) GLF_HIP(ctx, hipMemcpyAsync(h_norms, w.norms.p, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+// =====================================================================================
+// Residual || (I - X X^T) A X ||_F  (hpc/inverse_power_it.c:49-80) as || AX - X (X^T AX) ||_F
+// =====================================================================================
+
+constexpr int GRAM_ROWS = 1024; // rows per Gram workgroup chunk
+
+// Gpart[chunk][a][b] = sum_{i in chunk} X[i][a] * Y[i][b]; one wave per 32x32 (a,b) tile.
+__global__ __launch_bounds__(64) void k_gram(const float *__restrict__ X, const float *__restrict__ Y, unsigned p32,
+                                              unsigned ld, float *__restrict__ Gpart)
+{
+    const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+    const int mb = ld / 32;
+    const int ta = blockIdx.x / mb, tb = blockIdx.x % mb;
+    const unsigned r0 = blockIdx.y * GRAM_ROWS;
+    const unsigned r1 = min(r0 + GRAM_ROWS, p32);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (unsigned i = r0 + half; i < r1; i += 2) // p32 even: both halves stay in range together
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[(size_t)i * ld + 32 * ta + l31], Y[(size_t)i * ld + 32 * tb + l31], acc,
+                                                   0, 0, 0);
+    float *g = Gpart + (size_t)blockIdx.y * ld * ld;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int a = 32 * ta + (r & 3) + 8 * (r >> 2) + 4 * half;
+        g[(size_t)a * ld + 32 * tb + l31] = acc[r];
+    }
+}
+
+__global__ void k_gram_sum(const float *__restrict__ Gpart, int nchunks, unsigned ld, float *__restrict__ G)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ld * ld) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += (double)Gpart[(size_t)c * ld * ld + e];
+    G[e] = (float)s;
+}
+
+// partial[blk][b] = sum_i (Y[i][b] - sum_a X[i][a] G[a][b])^2
+__global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, const float *__restrict__ Y,
+                                                const float *__restrict__ G, unsigned p, unsigned ld, unsigned m,
+                                                double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    __shared__ float xrow[8][256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    double v[1] = {0.0};
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned r0 = 0; r0 < RED_ROWS; r0 += nrl) {
+        const unsigned i = base + r0 + rl;
+        const bool ok = i < p;
+        __syncthreads();
+        xrow[rl][col] = ok ? X[(size_t)i * ld + col] : 0.f;
+        __syncthreads();
+        if (ok && col < (int)m) {
+            float s = Y[(size_t)i * ld + col];
+            for (unsigned a = 0; a < m; ++a) s = fmaf(-xrow[rl][a], G[(size_t)a * ld + col], s);
+            v[0] += (double)s * (double)s;
+        }
+        if (base + r0 + nrl > p && base + r0 >= p) break; // uniform: whole group past the end
+    }
+    block_col_reduce<1>(v, ld, partial, sh);
+}
+
+struct ResWork {
+    DevBuf<float> AX, Gpart, G;
+    DevBuf<double> partial, sums;
+    int nchunks = 0;
+    int init(glf_ctx *ctx, unsigned p, unsigned ld)
+    {
+        const unsigned p32 = (unsigned)round_up(p, 32);
+        nchunks = (int)ceil_div(p32, GRAM_ROWS);
+        GLF_TRY(AX.alloc(ctx, (size_t)p32 * ld));
+        GLF_HIP(ctx, hipMemsetAsync(AX.p, 0, sizeof(float) * (size_t)p32 * ld, ctx->stream));
+        GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
+        GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
+        GLF_TRY(partial.alloc(ctx, (size_t)ceil_div(p, RED_ROWS) * ld));
+        GLF_TRY(sums.alloc(ctx, ld));
+        return GLF_OK;
+    }
+};
+
+static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
+                        unsigned ld, double *h_out)
+{
+    const unsigned p32 = (unsigned)round_up(p, 32);
+    const int nblk = (int)ceil_div(p, RED_ROWS);
+    hipStream_t st = ctx->stream;
+    GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld));
+    const int mb = ld / 32;
+    hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X, w.AX.p, p32, ld, w.Gpart.p);
+    hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 255) / 256), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
+    hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X, w.AX.p, w.G.p, p, ld, m, w.partial.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, w.partial.p, nblk, (int)ld, w.sums.p);
+    GLF_LAUNCH_CHECK(ctx);
+    std::vector<double> h(ld);
+    GLF_HIP(ctx, hipMemcpyAsync(h.data(), w.sums.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    double ss = 0.0;
+    for (unsigned c = 0; c < m; ++c) ss += h[c];
+    *h_out = std::sqrt(ss);
+    return GLF_OK;
+}
+
+int residual_norm(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, unsigned m, unsigned ld,
+                  float * /*AX_scratch*/, double *out)
+{
+    ResWork w;
+    GLF_TRY(w.init(ctx, p, ld));
+    return residual_dev(ctx, w, A, lda, p, X, m, ld, out);
+}
+
+// =====================================================================================
+// InversePowerIteration, hpc/inverse_power_it.c:86-252
+// =====================================================================================
+
+int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
+                            const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
+                            float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats)
+{
+    if (m == 0 || m > p || !valid_ld(ld) || m > ld)
+        return set_error(ctx, GLF_ERR_INVALID, "inverse_power_iteration: m=%u ld=%u p=%u (m <= 256 supported)", m, ld, p);
+    if (opti_gs < 1) opti_gs = 1; // hpc/image_processing.c:128-140
+    const unsigned p32 = (unsigned)round_up(p, 32);
+    const size_t n = (size_t)p32 * ld;
+    hipStream_t st = ctx->stream;
+
+    DevBuf<float> X, Xb;
+    GLF_TRY(X.alloc(ctx, n));
+    GLF_TRY(Xb.alloc(ctx, n));
+    // X0: host double [m][p] (vector after vector) -> device float [p32][ld]
+    {
+        std::vector<double> own;
+        if (!h_X0) {
+            own.resize((size_t)m * p);
+            glf_random_vectors(own.data(), p, m, 1);
+            h_X0 = own.data();
+        }
+        std::vector<float> h(n, 0.f);
+        for (unsigned j = 0; j < m; ++j)
+            for (unsigned i = 0; i < p; ++i) h[(size_t)i * ld + j] = (float)h_X0[(size_t)j * p + i];
+        GLF_HIP(ctx, hipMemcpyAsync(X.p, h.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+    }
+    GsWork gs;
+    GLF_TRY(gs.init(ctx, p, ld));
+    CgWork cg;
+    GLF_TRY(cg.init(ctx, p, ld));
+    ResWork rs;
+    GLF_TRY(rs.init(ctx, p, ld));
+    hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
+    GLF_LAUNCH_CHECK(ctx);
+
+    GLF_TRY(orthonormalise_dev(ctx, X.p, p, m, ld, gs.partial.p, gs.coef.p, gs.norms.p)); // :95
+    // The reference leaves X_k_before_orth unset when the loop never runs (:97-101); define it.
+    GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+    double r_norm = 0.0;
+    GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :159
+    int it = 0, inner_total = 0, rc = GLF_OK;
+    while (r_norm > epsilon) { // :161
+        if (it >= max_outer) {
+            rc = set_error(ctx, GLF_ERR_NOCONV, "inverse iteration: residual %g > %g after %d outer iterations", r_norm,
+                           epsilon, it);
+            break;
+        }
+        ++it;
+        int inner = 0;
+        GLF_TRY(block_pcg_work(ctx, cg, A, lda, p, X.p, m, ld, inner_rtol, 10 * (int)p + 100, &inner)); // :165-168
+        inner_total += inner;
+        GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st)); // CopyVecs :171
+        if (it % opti_gs == 0)
+            GLF_TRY(orthonormalise_dev(ctx, X.p, p, m, ld, gs.partial.p, gs.coef.p, gs.norms.p)); // :174-177
+        GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :180
+    }
+    if (opti_gs != 1 && (it % opti_gs) != 0)
+        GLF_TRY(orthonormalise_dev(ctx, X.p, p, m, ld, gs.partial.p, gs.coef.p, gs.norms.p)); // :183-186
+
+    if (h_eigvals) { // eigenvalues = 1 / norms, :204
+        std::vector<double> nr(m);
+        GLF_HIP(ctx, hipMemcpyAsync(nr.data(), gs.norms.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+        for (unsigned j = 0; j < m; ++j) h_eigvals[j] = 1.0 / nr[j];
+    }
+    if (d_eigvecs) { // NormaliseVecs(X_k_before_orth), :230
+        GLF_TRY(normalise_dev(ctx, Xb.p, p, m, ld, gs.partial.p, gs.norms.p));
+        GLF_HIP(ctx, hipMemcpyAsync(d_eigvecs, Xb.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+    }
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    if (stats) {
+        stats->outer_its = it;
+        stats->inner_its_total = inner_total;
+        stats->residual = r_norm;
+    }
+    return rc;
+}
+
+} // namespace glf

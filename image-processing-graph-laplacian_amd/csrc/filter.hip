@@ -1,0 +1,118 @@
+// filter.hip -- spectral filter reconstruction (hpc/display.c:58-83):
+//   right = Phi^T y                (m reductions over all pixels)
+//   z     = y + gain * Phi (f(Pi) right);  z > 255 -> 255;  (png_byte) cast
+// Both kernels stream Phi (N x ld floats) once: HBM-bandwidth bound,
+// 4 N ld + N bytes each.
+#include "glf_internal.hpp"
+
+namespace glf {
+
+// partial[blk][j] = sum_{pix in blk} Phi[pix][j] * y[pix]
+__global__ __launch_bounds__(256) void k_phi_t_y(const float *__restrict__ phi, const uint8_t *__restrict__ img, int64_t pix0,
+                                                  int64_t pix1, unsigned ld, double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    const int64_t base = pix0 + (int64_t)blockIdx.x * 1024;
+    float acc = 0.f;
+    double s = 0.0;
+    int cnt = 0;
+    for (int64_t r = rl; r < 1024; r += nrl) {
+        const int64_t px = base + r;
+        if (px >= pix1) break;
+        acc = fmaf(phi[(size_t)px * ld + col], (float)img[px], acc);
+        if (++cnt == 32) { // bounded f32 chains, f64 across them
+            s += (double)acc;
+            acc = 0.f;
+            cnt = 0;
+        }
+    }
+    s += (double)acc;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < ld) {
+        double t = 0.0;
+        for (int r = 0; r < nrl; ++r) t += sh[r * ld + col];
+        partial[(size_t)blockIdx.x * ld + col] = t;
+    }
+}
+
+__global__ void k_cols_sum(const double *__restrict__ in, int nrows, unsigned ld, double *__restrict__ out)
+{
+    // one workgroup per column chunk: 256 threads stride the rows, tree-reduce in LDS (fixed order)
+    __shared__ double sh[256];
+    const unsigned c = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += 256) s += in[(size_t)r * ld + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sh[0];
+}
+
+int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0, int64_t pix1, unsigned /*m*/, unsigned ld,
+            double *d_c)
+{
+    if (!valid_ld(ld) || pix0 > pix1) return set_error(ctx, GLF_ERR_INVALID, "phi_t_y: ld=%u", ld);
+    if (pix0 == pix1) {
+        GLF_HIP(ctx, hipMemsetAsync(d_c, 0, sizeof(double) * ld, ctx->stream));
+        return GLF_OK;
+    }
+    const int nblk = (int)ceil_div(pix1 - pix0, 1024);
+    DevBuf<double> part;
+    GLF_TRY(part.alloc(ctx, (size_t)nblk * ld));
+    hipLaunchKernelGGL(k_phi_t_y, dim3(nblk), dim3(256), 0, ctx->stream, d_phi, d_img, pix0, pix1, ld, part.p);
+    hipLaunchKernelGGL(k_cols_sum, dim3(ld), dim3(256), 0, ctx->stream, part.p, nblk, ld, d_c);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+// z[pix] = y + gain * sum_j Phi[pix][j] w[j]; LD/4 lanes per pixel, float4 each.
+template <int LD>
+__global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict__ img, const float *__restrict__ phi,
+                                                       int64_t pix0, int64_t pix1, const float *__restrict__ w, float gain,
+                                                       uint8_t *__restrict__ out, float *__restrict__ zf)
+{
+    constexpr int LPP = LD / 4;       // lanes per pixel (8 .. 64)
+    constexpr int PPB = 256 / LPP;    // pixels per block pass
+    const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const float4 wq = reinterpret_cast<const float4 *>(w)[q];
+    for (int64_t px = pix0 + (int64_t)blockIdx.x * PPB + pl; px < pix1; px += (int64_t)gridDim.x * PPB) {
+        const float4 f = reinterpret_cast<const float4 *>(phi + (size_t)px * LD)[q];
+        float s = f.x * wq.x + f.y * wq.y + f.z * wq.z + f.w * wq.w;
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (q == 0) {
+            float z = fmaf(gain, s, (float)img[px]); // MatAXPY(z, 3.0, Lapl_y), hpc/display.c:73
+            if (zf) zf[px] = z;
+            z = z > 255.f ? 255.f : z;               // AboveXSetY(z, 255, 255), :76
+            z = z > 0.f ? z : 0.f;                   // negative -> 0 (survey quirk Q4; also maps NaN to 0)
+            out[px] = (uint8_t)z;                    // (png_byte) cast = truncation, hpc/utils.c:525
+        }
+    }
+}
+
+int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1, unsigned /*m*/,
+                 unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf)
+{
+    if (!valid_ld(ld) || pix0 > pix1) return set_error(ctx, GLF_ERR_INVALID, "apply_filter: ld=%u", ld);
+    if (pix0 == pix1) return GLF_OK;
+    const int ppb = 256 / (ld / 4);
+    int64_t nblk = ceil_div(pix1 - pix0, ppb);
+    if (nblk > 8192) nblk = 8192; // grid-stride the rest
+    dim3 grid((unsigned)nblk), block(256);
+    switch (ld) {
+    case 32: hipLaunchKernelGGL(k_apply_filter<32>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
+    case 64: hipLaunchKernelGGL(k_apply_filter<64>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
+    case 128: hipLaunchKernelGGL(k_apply_filter<128>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
+    case 256: hipLaunchKernelGGL(k_apply_filter<256>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
+    }
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+} // namespace glf

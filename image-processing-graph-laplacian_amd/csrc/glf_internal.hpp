@@ -1,0 +1,172 @@
+// glf_internal.hpp -- shared declarations of the HIP implementation behind include/glf.h.
+// gfx950 (MI355X / CDNA4) only; wave = 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/glf.h"
+
+struct glf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    glf_comm comm{};
+    bool has_comm = false;
+    char last_error[512] = {0};
+    hipDeviceProp_t prop{};
+    // reusable events for stage timing
+    hipEvent_t ev[8] = {};
+};
+
+namespace glf {
+
+constexpr int WAVE = 64;
+
+inline int set_error(glf_ctx *ctx, int status, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->last_error, sizeof(ctx->last_error), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+#define GLF_HIP(ctx, call)                                                                    \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return glf::set_error((ctx), e__ == hipErrorOutOfMemory ? GLF_ERR_NOMEM : GLF_ERR_HIP, \
+                                  "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+    } while (0)
+
+#define GLF_TRY(expr)                 \
+    do {                              \
+        int s__ = (expr);             \
+        if (s__ != GLF_OK) return s__; \
+    } while (0)
+
+#define GLF_LAUNCH_CHECK(ctx) GLF_HIP(ctx, hipGetLastError())
+
+inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+inline int64_t ceil_div(int64_t x, int64_t q) { return (x + q - 1) / q; }
+// Leading dimension of vector blocks: m rounded up to a power of two in {32,64,128,256}
+// (the column-reduction kernels map 256 threads onto 256/ld row lanes x ld columns).
+inline unsigned ld_for(unsigned m) { unsigned ld = 32; while (ld < m) ld <<= 1; return ld; }
+inline bool valid_ld(unsigned ld) { return ld == 32 || ld == 64 || ld == 128 || ld == 256; }
+
+// RAII device buffer tied to a context's stream (freed with hipFree at scope exit).
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(glf_ctx *ctx, size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return GLF_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_error(ctx, GLF_ERR_NOMEM, "hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        return GLF_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    T *take()
+    {
+        T *q = p;
+        p = nullptr;
+        n = 0;
+        return q;
+    }
+};
+
+// Kernel-side description of the Gaussian kernel (hpc/affinity.c:59-121): the
+// exponent is  -(dr^2+dc^2)/h_loc^2 - dv^2/h_val^2; we evaluate it as
+// exp2(-(q*s_loc + u*s_val)) with s = log2(e)/h^2 so one v_exp_f32 does both
+// reference exps. dr, dc, dv are exact small integers in f32.
+struct KernelCoef {
+    float s_loc; // log2(e) / h_loc^2 (0 for the photometric kernel)
+    float s_val; // log2(e) / h_val^2 (0 for the spatial kernel)
+};
+KernelCoef make_coef(int kernel, float h_loc, float h_val);
+
+__device__ __forceinline__ float kernel_eval(float dr, float dc, float dv, float s_loc, float s_val)
+{
+    const float q = fmaf(dc, dc, dr * dr);
+    const float t = fmaf(dv * dv, s_val, q * s_loc);
+    return __builtin_amdgcn_exp2f(-t);
+}
+
+// ---- stage implementations (device pointers, all on ctx->stream) -----------------
+
+// Sample table: float4 {row, col, value, 0} per sample + mask + device idx.
+struct SampleTables {
+    DevBuf<float4> samples;
+    DevBuf<uint8_t> mask;
+    DevBuf<uint32_t> idx;
+};
+int build_sample_tables(glf_ctx *ctx, const uint8_t *d_img, int width, int height, unsigned p,
+                        const unsigned *h_idx, SampleTables &out);
+
+// Partial degree D[i] = sum over pixels in rows [row0,row1) of K(sample i, pixel).
+int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
+                const float4 *d_samples, unsigned p, KernelCoef coef, double *d_degree);
+
+// K_A (scale = 1, diag untouched) or L_A (scale = -alpha, diagonal alpha * D_i).
+int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef,
+                        float *d_out, int64_t ld, bool laplacian, double alpha, const double *d_degree);
+int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, float *d_LA, int64_t ld,
+                      double alpha, const double *d_degree);
+
+// Eigensolver pieces (eigen.hip)
+struct EigWork; // opaque workspace
+int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y,
+                 unsigned mld);
+int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms);
+int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms);
+int residual_norm(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
+                  unsigned ld, float *AX_scratch, double *out);
+int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, unsigned m, unsigned ld,
+              double rtol, int max_it, int *iters);
+int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
+                            const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
+                            float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats);
+
+// Nystroem contraction (nystroem.hip): Phi[pix][j] = sum_i scale*K(sample i, pix) * Psi[i][j]
+// for pixels [pix0, pix1). raster != 0: row = pix; else sample-first (rows of sample pixels skipped).
+// cpart (optional): m doubles, += sum over NON-sample pixels of Phi[pix][j] * y[pix].
+int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
+                      const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
+                      KernelCoef coef, float scale, const float *d_psi, unsigned m, unsigned ld,
+                      float *d_phi, int raster, double *d_c, float *kernel_ms);
+// Phi rows of the sample pixels <- Phi_A rows (hpc/nystroem.c:25-34 + hpc/utils.c:149-152)
+int scatter_sample_rows(glf_ctx *ctx, const float *d_phiA, unsigned p, unsigned ld, const uint32_t *d_idx,
+                        float *d_phi, int raster, const uint8_t *d_img, double *d_c, unsigned m);
+int permute_rows(glf_ctx *ctx, const float *d_in, float *d_out, int64_t N, unsigned ld,
+                 const uint32_t *d_idx, unsigned p);
+
+// filter.hip
+int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0, int64_t pix1, unsigned m,
+            unsigned ld, double *d_c);
+int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1,
+                 unsigned m, unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf);
+
+} // namespace glf

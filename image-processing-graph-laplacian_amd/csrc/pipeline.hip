@@ -1,0 +1,395 @@
+// pipeline.hip -- the C-ABI stage entry points (mirror of hpc/*.h) and the whole
+// approximate path glf_image_processing (hpc/image_processing.c:183-277).
+#include "glf_internal.hpp"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace glf {
+
+static void shard_rows(const glf_ctx *ctx, int height, int *row0, int *row1)
+{
+    const int G = ctx->has_comm ? ctx->comm.size : 1, g = ctx->has_comm ? ctx->comm.rank : 0;
+    *row0 = (int)((int64_t)g * height / G);
+    *row1 = (int)((int64_t)(g + 1) * height / G);
+}
+
+static int allreduce_f64(glf_ctx *ctx, double *d, size_t n)
+{
+    if (!ctx->has_comm) return GLF_OK;
+    if (ctx->comm.allreduce_sum_f64(ctx->comm.user, d, n) != 0)
+        return set_error(ctx, GLF_ERR_COMM, "allreduce_sum_f64 callback failed");
+    return GLF_OK;
+}
+
+// Psi[i][j] = scale * Phi_A[i][j] * pinv[j]   (part_lower = phi_A * Pi^-1, hpc/nystroem.c:41; scale = -alpha)
+__global__ void k_make_psi(const float *__restrict__ phiA, const float *__restrict__ pinv, unsigned p, unsigned ld, unsigned m,
+                           float scale, float *__restrict__ psi)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned i = (unsigned)(e / ld), j = (unsigned)(e % ld);
+    if (i >= p) return;
+    psi[e] = (j < m) ? scale * (phiA[e] * pinv[j]) : 0.f;
+}
+
+__global__ void k_diag_inverse(const float *__restrict__ x, unsigned n, float *__restrict__ y)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 1.0f / x[i]; // InverseDiagMat, hpc/utils.c:578-579
+}
+
+static int sum_host(glf_ctx *ctx, const double *d_v, unsigned n, double *out)
+{
+    std::vector<double> h(n);
+    GLF_HIP(ctx, hipMemcpyAsync(h.data(), d_v, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (unsigned i = 0; i < n; ++i) s += h[i];
+    *out = s;
+    return GLF_OK;
+}
+
+} // namespace glf
+
+using namespace glf;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------
+// Stage API
+// ------------------------------------------------------------------------------------------
+
+int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const uint8_t *d_img, int width, int height,
+                                unsigned sample_size, const unsigned *sample_indices, int kernel, float h_loc,
+                                float h_val)
+{
+    if (!ctx || !K_B || !d_img || width <= 0 || height <= 0) return GLF_ERR_INVALID;
+    if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
+    const unsigned p = sample_size;
+    SampleTables tb;
+    GLF_TRY(build_sample_tables(ctx, d_img, width, height, p, sample_indices, tb));
+    const KernelCoef coef = make_coef(kernel, h_loc, h_val);
+    DevBuf<double> deg;
+    GLF_TRY(deg.alloc(ctx, p));
+    int row0, row1;
+    shard_rows(ctx, height, &row0, &row1);
+    GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
+    GLF_TRY(allreduce_f64(ctx, deg.p, p));
+    if (K_A) {
+        const int64_t lda = round_up(p, 32);
+        GLF_TRY(glf_mat_create_dense(ctx, K_A, p, p, lda)); // zero-filled incl. padding
+        GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, K_A->data, lda, false, 0.0, nullptr));
+    }
+    std::memset(K_B, 0, sizeof(*K_B));
+    K_B->kind = GLF_MAT_KERNEL_B;
+    K_B->rows = p;
+    K_B->cols = (int64_t)width * height - p;
+    K_B->img = d_img;
+    K_B->width = width;
+    K_B->height = height;
+    K_B->p = p;
+    K_B->scale = 1.0f;
+    K_B->h_loc = h_loc;
+    K_B->h_val = h_val;
+    K_B->kernel = kernel;
+    K_B->samples = reinterpret_cast<const float *>(tb.samples.take());
+    K_B->mask = tb.mask.take();
+    K_B->idx = tb.idx.take();
+    K_B->degree = deg.take();
+    K_B->owns_desc = 1;
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+int glf_ComputeLaplacianMatrix(glf_ctx *ctx, glf_mat *L_A, glf_mat *L_B, const glf_mat *K_A, const glf_mat *K_B,
+                               double *alpha_out)
+{
+    if (!ctx || !L_A || !K_B || K_B->kind != GLF_MAT_KERNEL_B || !K_B->degree) return GLF_ERR_INVALID;
+    const unsigned p = K_B->p;
+    if (K_A && (K_A->kind != GLF_MAT_DENSE || K_A->rows != p || K_A->cols != p))
+        return set_error(ctx, GLF_ERR_INVALID, "K_A must be dense p x p");
+    // alpha = 1 / VecMean(D_A), hpc/laplacian.c:29 + hpc/utils.c:378-388
+    double sum = 0.0;
+    GLF_TRY(sum_host(ctx, K_B->degree, p, &sum));
+    const double alpha = 1.0 / (sum / (double)p);
+    const int64_t lda = round_up(p, 32);
+    GLF_TRY(glf_mat_create_dense(ctx, L_A, p, p, lda));
+    const KernelCoef coef = make_coef(K_B->kernel, K_B->h_loc, K_B->h_val);
+    if (K_A)
+        GLF_TRY(laplacian_from_KA(ctx, K_A->data, K_A->ld, p, L_A->data, lda, alpha, K_B->degree));
+    else
+        GLF_TRY(build_sample_matrix(ctx, reinterpret_cast<const float4 *>(K_B->samples), p, coef, L_A->data, lda, true,
+                                    alpha, K_B->degree));
+    if (L_B) { // L_B = -alpha K_B, hpc/laplacian.c:37-38: same generator, other scale (shares tables)
+        *L_B = *K_B;
+        L_B->scale = (float)(-alpha);
+        L_B->owns_desc = 0;
+    }
+    if (alpha_out) *alpha_out = alpha;
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+int glf_InversePowerIteration(glf_ctx *ctx, const glf_mat *A, unsigned m, glf_mat *eigenvectors, glf_mat *eigenvalues,
+                              int optiGramSchmidt, double epsilon, double inner_rtol, int max_outer, const double *X0,
+                              glf_eig_stats *stats)
+{
+    if (!ctx || !A || A->kind != GLF_MAT_DENSE || A->rows != A->cols) return GLF_ERR_INVALID;
+    const unsigned p = (unsigned)A->rows;
+    if (m == 0 || m >= p) return set_error(ctx, GLF_ERR_INVALID, "need 0 < m < p (m=%u p=%u)", m, p);
+    if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "m = %u > 256 eigenpairs not supported", m);
+    const unsigned ld = ld_for(m);
+    const unsigned p32 = (unsigned)round_up(p, 32);
+    glf_mat vecs;
+    GLF_TRY(glf_mat_create_dense(ctx, &vecs, p32, m, ld));
+    vecs.rows = p;
+    std::vector<double> lam(m);
+    int rc = inverse_power_iteration(ctx, A->data, A->ld, p, m, ld, X0, optiGramSchmidt, epsilon, inner_rtol,
+                                     max_outer > 0 ? max_outer : 100000, vecs.data, lam.data(), stats);
+    if (rc != GLF_OK && rc != GLF_ERR_NOCONV) {
+        glf_mat_destroy(ctx, &vecs);
+        return rc;
+    }
+    if (eigenvalues) {
+        int rc2 = glf_mat_create_diag(ctx, eigenvalues, m);
+        if (rc2 != GLF_OK) return rc2;
+        std::vector<float> lf(m);
+        for (unsigned j = 0; j < m; ++j) lf[j] = (float)lam[j];
+        GLF_TRY(glf_memcpy_h2d(ctx, eigenvalues->data, lf.data(), sizeof(float) * m));
+    }
+    if (eigenvectors) *eigenvectors = vecs;
+    else glf_mat_destroy(ctx, &vecs);
+    return rc;
+}
+
+int glf_OrthonormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms)
+{
+    if (!ctx || !X || X->kind != GLF_MAT_DENSE) return GLF_ERR_INVALID;
+    return orthonormalise(ctx, X->data, (unsigned)X->rows, (unsigned)X->cols, (unsigned)X->ld, norms);
+}
+
+int glf_NormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms)
+{
+    if (!ctx || !X || X->kind != GLF_MAT_DENSE) return GLF_ERR_INVALID;
+    return normalise(ctx, X->data, (unsigned)X->rows, (unsigned)X->cols, (unsigned)X->ld, norms);
+}
+
+int glf_InverseDiagMat(glf_ctx *ctx, const glf_mat *x, glf_mat *inv)
+{
+    if (!ctx || !x || !inv || x->kind != GLF_MAT_DIAG) return GLF_ERR_INVALID;
+    GLF_TRY(glf_mat_create_diag(ctx, inv, x->rows));
+    const unsigned n = (unsigned)x->rows;
+    hipLaunchKernelGGL(k_diag_inverse, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, x->data, n, inv->data);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+int glf_Nystroem(glf_ctx *ctx, const glf_mat *B, const glf_mat *phi_A, const glf_mat *Pi_A_Inv, glf_mat *phi)
+{
+    if (!ctx || !B || !phi_A || !Pi_A_Inv || !phi) return GLF_ERR_INVALID;
+    if (B->kind != GLF_MAT_KERNEL_B || phi_A->kind != GLF_MAT_DENSE || Pi_A_Inv->kind != GLF_MAT_DIAG)
+        return set_error(ctx, GLF_ERR_INVALID, "Nystroem: B must be a KERNEL_B descriptor, phi_A dense, Pi_A_Inv diagonal");
+    const unsigned p = B->p, m = (unsigned)phi_A->cols, ld = (unsigned)phi_A->ld;
+    if (phi_A->rows != p || Pi_A_Inv->rows != m || !valid_ld(ld))
+        return set_error(ctx, GLF_ERR_INVALID, "Nystroem: shape mismatch (p=%u, phi_A %lld x %u ld %u)", p,
+                         (long long)phi_A->rows, m, ld);
+    const int64_t N = (int64_t)B->width * B->height;
+    DevBuf<float> psi;
+    GLF_TRY(psi.alloc(ctx, (size_t)p * ld));
+    hipLaunchKernelGGL(k_make_psi, dim3((unsigned)ceil_div((int64_t)p * ld, 256)), dim3(256), 0, ctx->stream, phi_A->data,
+                       Pi_A_Inv->data, p, ld, m, B->scale, psi.p);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_TRY(glf_mat_create_dense(ctx, phi, N, m, ld));
+    phi->row_order = GLF_ROWS_SAMPLE_FIRST;
+    const KernelCoef coef = make_coef(B->kernel, B->h_loc, B->h_val);
+    GLF_TRY(nystroem_contract(ctx, B->img, B->width, B->height, 0, N, reinterpret_cast<const float4 *>(B->samples), B->mask,
+                              B->idx, p, coef, B->scale, psi.p, m, ld, phi->data, 0, nullptr, nullptr));
+    GLF_TRY(scatter_sample_rows(ctx, phi_A->data, p, ld, B->idx, phi->data, 0, B->img, nullptr, m));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+int glf_Permutation(glf_ctx *ctx, const glf_mat *in, const unsigned *sample_indices, unsigned num, glf_mat *out)
+{
+    if (!ctx || !in || !out || in->kind != GLF_MAT_DENSE || !sample_indices) return GLF_ERR_INVALID;
+    DevBuf<uint32_t> idx;
+    GLF_TRY(idx.alloc(ctx, num));
+    GLF_TRY(glf_memcpy_h2d(ctx, idx.p, sample_indices, sizeof(uint32_t) * num));
+    GLF_TRY(glf_mat_create_dense(ctx, out, in->rows, in->cols, in->ld));
+    out->row_order = GLF_ROWS_RASTER;
+    GLF_TRY(permute_rows(ctx, in->data, out->data, in->rows, (unsigned)in->ld, idx.p, num));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf_mat *phi, const glf_mat *Pi, unsigned width,
+                                   unsigned height, float gain, uint8_t *d_out, float *d_zf)
+{
+    if (!ctx || !d_img || !phi || !Pi || !d_out) return GLF_ERR_INVALID;
+    const int64_t N = (int64_t)width * height;
+    const unsigned m = (unsigned)phi->cols, ld = (unsigned)phi->ld;
+    if (phi->kind != GLF_MAT_DENSE || phi->rows != N || Pi->kind != GLF_MAT_DIAG || Pi->rows != m || !valid_ld(ld))
+        return set_error(ctx, GLF_ERR_INVALID, "ComputeResultFromLaplacian: shape mismatch");
+    if (phi->row_order == GLF_ROWS_SAMPLE_FIRST)
+        return set_error(ctx, GLF_ERR_INVALID, "phi is in sample-first order: call glf_Permutation first (hpc/image_processing.c:250)");
+    DevBuf<double> c;
+    GLF_TRY(c.alloc(ctx, ld));
+    GLF_TRY(phi_t_y(ctx, phi->data, d_img, 0, N, m, ld, c.p)); // right = phi^T z, hpc/display.c:66
+    std::vector<double> hc(ld);
+    std::vector<float> hp(m), hw(ld, 0.f);
+    GLF_TRY(glf_memcpy_d2h(ctx, hc.data(), c.p, sizeof(double) * ld));
+    GLF_TRY(glf_memcpy_d2h(ctx, hp.data(), Pi->data, sizeof(float) * m));
+    for (unsigned j = 0; j < m; ++j) hw[j] = (float)((double)hp[j] * hc[j]); // left = phi Pi, :64
+    DevBuf<float> w;
+    GLF_TRY(w.alloc(ctx, ld));
+    GLF_TRY(glf_memcpy_h2d(ctx, w.p, hw.data(), sizeof(float) * ld));
+    GLF_TRY(apply_filter(ctx, d_img, phi->data, 0, N, m, ld, w.p, gain, d_out, d_zf));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole approximate path
+// ------------------------------------------------------------------------------------------
+
+int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t *d_img, int width, int height,
+                         uint8_t *d_out, float *d_zf, double *eigvals_out, glf_stats *stats)
+{
+    if (!ctx || !d_img || !d_out || width <= 0 || height <= 0) return GLF_ERR_INVALID;
+    glf_options opt;
+    glf_options_default(&opt);
+    if (opt_in) {
+        if (opt_in->struct_size != sizeof(glf_options))
+            return set_error(ctx, GLF_ERR_INVALID, "glf_options.struct_size %u != %zu", opt_in->struct_size, sizeof(glf_options));
+        opt = *opt_in;
+    }
+    if (opt.kernel < GLF_KERNEL_BILATERAL || opt.kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", opt.kernel);
+    const int64_t N = (int64_t)width * height;
+    if (N >= (int64_t)1 << 31) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too large");
+    hipStream_t st = ctx->stream;
+    glf_stats S{};
+
+    // p = width*height*0.01 (truncating), hpc/image_processing.c:187; Sampling rewrites it, :191-193
+    unsigned p = opt.num_samples ? opt.num_samples : (unsigned)((double)N * opt.sample_frac);
+    unsigned *h_idx = nullptr;
+    {
+        int rc = glf_Sampling(width, height, &p, &h_idx);
+        if (rc != GLF_OK || p < 2) {
+            std::free(h_idx);
+            return set_error(ctx, GLF_ERR_INVALID, "sampling failed (requested %u samples on %dx%d)", p, width, height);
+        }
+    }
+    struct FreeIdx {
+        unsigned *q;
+        ~FreeIdx() { std::free(q); }
+    } free_idx{h_idx};
+    // GetNumberEigenvalues, hpc/image_processing.c:96-108
+    unsigned m = opt.num_eigvals;
+    if (m == 0 || m >= p) m = p - 1;
+    if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "num_eigvals = %u > 256 not supported (p = %u)", m, p);
+    const unsigned ld = ld_for(m);
+    const unsigned p32 = (unsigned)round_up(p, 32);
+    const KernelCoef coef = make_coef(opt.kernel, opt.h_loc, opt.h_val);
+    int row0, row1;
+    shard_rows(ctx, height, &row0, &row1);
+    const int64_t pix0 = (int64_t)row0 * width, pix1 = (int64_t)row1 * width;
+    S.p = p;
+    S.m = m;
+    S.row0 = row0;
+    S.row1 = row1;
+
+    GLF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    // ---- affinity: sample tables + degree (K_B generated on the fly) -------------------------
+    SampleTables tb;
+    GLF_TRY(build_sample_tables(ctx, d_img, width, height, p, h_idx, tb));
+    DevBuf<double> deg;
+    GLF_TRY(deg.alloc(ctx, p));
+    GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
+    GLF_TRY(allreduce_f64(ctx, deg.p, p));
+    GLF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    // ---- Laplacian ---------------------------------------------------------------------------
+    double dsum = 0.0;
+    GLF_TRY(sum_host(ctx, deg.p, p, &dsum));
+    const double alpha = 1.0 / (dsum / (double)p);
+    S.alpha = alpha;
+    DevBuf<float> LA;
+    GLF_TRY(LA.alloc(ctx, (size_t)p * p32));
+    GLF_HIP(ctx, hipMemsetAsync(LA.p, 0, sizeof(float) * (size_t)p * p32, st));
+    GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, p32, true, alpha, deg.p));
+    GLF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    // ---- eigenpairs --------------------------------------------------------------------------
+    DevBuf<float> phiA;
+    GLF_TRY(phiA.alloc(ctx, (size_t)p32 * ld));
+    std::vector<double> lam(m);
+    {
+        std::vector<double> X0((size_t)m * p);
+        glf_random_vectors(X0.data(), p, m, opt.seed);
+        int rc = inverse_power_iteration(ctx, LA.p, p32, p, m, ld, X0.data(), opt.opti_gs, opt.epsilon, opt.inner_rtol,
+                                         opt.max_outer > 0 ? opt.max_outer : 100000, phiA.p, lam.data(), &S.eig);
+        if (rc != GLF_OK) return rc;
+    }
+    LA.release();
+    if (eigvals_out)
+        for (unsigned j = 0; j < m; ++j) eigvals_out[j] = lam[j];
+    GLF_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    // ---- Nystroem extension, written straight in raster order (Permutation folded in) ----------
+    DevBuf<float> psi, pinv, phi, w;
+    DevBuf<double> c;
+    GLF_TRY(psi.alloc(ctx, (size_t)p * ld));
+    GLF_TRY(pinv.alloc(ctx, ld));
+    GLF_TRY(w.alloc(ctx, ld));
+    GLF_TRY(c.alloc(ctx, ld));
+    {
+        std::vector<float> hp(ld, 0.f);
+        for (unsigned j = 0; j < m; ++j) hp[j] = (float)(1.0 / lam[j]); // InverseDiagMat, hpc/utils.c:559-586
+        GLF_HIP(ctx, hipMemcpyAsync(pinv.p, hp.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(k_make_psi, dim3((unsigned)ceil_div((int64_t)p * ld, 256)), dim3(256), 0, st, phiA.p, pinv.p, p, ld, m,
+                       (float)(-alpha), psi.p);
+    GLF_LAUNCH_CHECK(ctx);
+    const int64_t npix = pix1 - pix0;
+    GLF_TRY(phi.alloc(ctx, (size_t)npix * ld));
+    float *phi_base = phi.p - (size_t)pix0 * ld; // rows addressed by absolute pixel index
+    GLF_HIP(ctx, hipMemsetAsync(c.p, 0, sizeof(double) * ld, st));
+    float kms = 0.f;
+    GLF_TRY(nystroem_contract(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, (float)(-alpha),
+                              psi.p, m, ld, phi_base, 1, c.p, &kms));
+    S.nystroem_launches = 1;
+    S.nystroem_kernel_ms = kms;
+    {
+        // sample rows of this shard <- Phi_A, and their share of c
+        unsigned i0 = 0, i1 = 0;
+        while (i0 < p && (int64_t)h_idx[i0] < pix0) ++i0;
+        i1 = i0;
+        while (i1 < p && (int64_t)h_idx[i1] < pix1) ++i1;
+        if (i1 > i0)
+            GLF_TRY(scatter_sample_rows(ctx, phiA.p + (size_t)i0 * ld, i1 - i0, ld, tb.idx.p + i0, phi_base, 1, d_img, c.p, m));
+    }
+    GLF_TRY(allreduce_f64(ctx, c.p, ld)); // right = phi^T y over all ranks' pixels
+    GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+    // ---- filter ------------------------------------------------------------------------------
+    {
+        std::vector<double> hc(ld);
+        GLF_HIP(ctx, hipMemcpyAsync(hc.data(), c.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+        std::vector<float> hw(ld, 0.f);
+        // f(Pi): MatPow(eigvals, 6) is a no-op in the reference (hpc/utils.c:721) => filter_pow = 1
+        for (unsigned j = 0; j < m; ++j) hw[j] = (float)(std::pow(lam[j], (double)(opt.filter_pow > 0 ? opt.filter_pow : 1)) * hc[j]);
+        GLF_HIP(ctx, hipMemcpyAsync(w.p, hw.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+    }
+    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, opt.gain, d_out, d_zf));
+    GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+    GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
+    GLF_HIP(ctx, hipEventElapsedTime(&S.ms_affinity, ctx->ev[0], ctx->ev[1]));
+    GLF_HIP(ctx, hipEventElapsedTime(&S.ms_laplacian, ctx->ev[1], ctx->ev[2]));
+    GLF_HIP(ctx, hipEventElapsedTime(&S.ms_eigen, ctx->ev[2], ctx->ev[3]));
+    GLF_HIP(ctx, hipEventElapsedTime(&S.ms_nystroem, ctx->ev[3], ctx->ev[4]));
+    GLF_HIP(ctx, hipEventElapsedTime(&S.ms_filter, ctx->ev[4], ctx->ev[5]));
+    GLF_HIP(ctx, hipEventElapsedTime(&S.ms_total, ctx->ev[0], ctx->ev[5]));
+    if (stats) *stats = S;
+    return GLF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,411 @@
+"""ctypes binding of libglf.so -- the C-ABI declared in include/glf.h.
+
+Python is plumbing only: torch tensors provide device memory and the current
+HIP stream, torch.distributed (backend "nccl" = RCCL) provides the collectives
+plugged into glf_comm. All compute happens in the HIP library; if libglf.so is
+missing this module raises at import time (there is no CPU fallback).
+
+Function names mirror the reference's stage functions (hpc/*.h) exactly as the
+C-ABI does: ComputeAffinityMatrices, ComputeLaplacianMatrix,
+InversePowerIteration, OrthonormaliseVecs, Nystroem, Permutation,
+ComputeResultFromLaplacian, plus image_processing for the whole path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglf.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libglf.so not found at %s: build it with `make` (or __graft_entry__.build()); "
+        "there is no CPU fallback for the HIP path" % LIB_PATH)
+_lib = C.CDLL(LIB_PATH)
+
+OK = 0
+ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_NODEVICE, ERR_COMM, ERR_NOCONV, ERR_IO, ERR_UNSUPPORTED = range(-1, -9, -1)
+MAT_DENSE, MAT_DIAG, MAT_KERNEL_B = 0, 1, 2
+ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
+KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL = 0, 1, 2
+
+# every symbol include/glf.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
+    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
+    "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_Sampling",
+    "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
+    "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
+    "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
+    "glf_options_default", "glf_image_processing", "glf_read_png", "glf_write_png",
+]
+
+
+class Mat(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("row_order", C.c_int32), ("rows", C.c_int64), ("cols", C.c_int64),
+        ("ld", C.c_int64), ("data", C.c_void_p), ("owns_data", C.c_int32),
+        ("img", C.c_void_p), ("samples", C.c_void_p), ("mask", C.c_void_p), ("idx", C.c_void_p),
+        ("width", C.c_int32), ("height", C.c_int32), ("p", C.c_uint32), ("scale", C.c_float),
+        ("h_loc", C.c_float), ("h_val", C.c_float), ("kernel", C.c_int32), ("degree", C.c_void_p),
+        ("owns_desc", C.c_int32),
+    ]
+
+
+class EigStats(C.Structure):
+    _fields_ = [("outer_its", C.c_int32), ("inner_its_total", C.c_int32), ("residual", C.c_double)]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("num_samples", C.c_uint32), ("sample_frac", C.c_double),
+        ("num_eigvals", C.c_uint32), ("opti_gs", C.c_int32), ("epsilon", C.c_double),
+        ("inner_rtol", C.c_double), ("max_outer", C.c_int32), ("seed", C.c_uint64), ("gain", C.c_float),
+        ("h_loc", C.c_float), ("h_val", C.c_float), ("kernel", C.c_int32), ("filter_pow", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("p", C.c_uint32), ("m", C.c_uint32), ("alpha", C.c_double), ("eig", EigStats),
+        ("ms_affinity", C.c_float), ("ms_laplacian", C.c_float), ("ms_eigen", C.c_float),
+        ("ms_nystroem", C.c_float), ("ms_filter", C.c_float), ("ms_total", C.c_float),
+        ("nystroem_launches", C.c_int32), ("nystroem_kernel_ms", C.c_float),
+        ("row0", C.c_int32), ("row1", C.c_int32),
+    ]
+
+
+ALLREDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Comm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("allreduce_sum_f32", ALLREDUCE_F32),
+                ("allreduce_sum_f64", ALLREDUCE_F64), ("user", C.c_void_p)]
+
+
+_lib.glf_strerror.restype = C.c_char_p
+_lib.glf_ctx_last_error.restype = C.c_char_p
+_lib.glf_ctx_last_error.argtypes = [C.c_void_p]
+_lib.glf_host_free.restype = None
+_lib.glf_options_default.restype = None
+
+
+class GlfError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _lib.glf_strerror(status).decode()
+        super().__init__("glf status %d (%s)%s" % (status, msg, (": " + detail) if detail else ""))
+
+
+def default_options(**kw):
+    opt = Options()
+    _lib.glf_options_default(C.byref(opt))
+    for k, v in kw.items():
+        if not hasattr(opt, k):
+            raise AttributeError("glf_options has no field %r" % k)
+        setattr(opt, k, v)
+    return opt
+
+
+# ---- host-side stages ---------------------------------------------------------------
+
+def Sampling(width, height, sample_size):
+    """hpc/sampling.c:6-33 -> (realised count, uint32 indices)."""
+    n = C.c_uint(sample_size)
+    ptr = C.POINTER(C.c_uint)()
+    rc = _lib.glf_Sampling(C.c_int(width), C.c_int(height), C.byref(n), C.byref(ptr))
+    if rc != OK:
+        raise GlfError(rc, "Sampling(%d, %d, %d)" % (width, height, sample_size))
+    idx = np.ctypeslib.as_array(ptr, shape=(max(n.value, 1),))[:n.value].astype(np.uint32).copy()
+    _lib.glf_host_free(ptr)
+    return idx
+
+
+def random_vectors(p, m, seed=1):
+    X0 = np.empty((m, p), dtype=np.float64)
+    rc = _lib.glf_random_vectors(X0.ctypes.data_as(C.c_void_p), C.c_uint(p), C.c_uint(m), C.c_uint64(seed))
+    if rc != OK:
+        raise GlfError(rc)
+    return X0
+
+
+def synth_image(width, height, seed=0):
+    out = np.empty((height, width), dtype=np.uint8)
+    rc = _lib.glf_synth_image(out.ctypes.data_as(C.c_void_p), C.c_int(width), C.c_int(height), C.c_uint64(seed))
+    if rc != OK:
+        raise GlfError(rc)
+    return out
+
+
+def read_png(path):
+    rows = C.POINTER(C.POINTER(C.c_uint8))()
+    w, h = C.c_int(), C.c_int()
+    rc = _lib.glf_read_png(path.encode(), C.byref(rows), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise GlfError(ERR_IO, path)
+    img = np.empty((h.value, w.value), dtype=np.uint8)
+    for r in range(h.value):
+        img[r] = np.ctypeslib.as_array(rows[r], shape=(w.value,))
+        _lib.glf_host_free(rows[r])
+    _lib.glf_host_free(rows)
+    return img
+
+
+def write_png(path, img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    rowptr = (C.POINTER(C.c_uint8) * h)()
+    for r in range(h):
+        rowptr[r] = C.cast(img.ctypes.data + r * w, C.POINTER(C.c_uint8))
+    rc = _lib.glf_write_png(path.encode(), rowptr, C.c_uint(w), C.c_uint(h))
+    if rc != 0:
+        raise GlfError(ERR_IO, path)
+
+
+# ---- device context --------------------------------------------------------------------
+
+class Context:
+    """One glf_ctx on one GPU, launching on torch's current stream of that device."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
+        self._ctx = C.c_void_p()
+        rc = _lib.glf_ctx_create(C.byref(self._ctx), C.c_int(device), C.c_void_p(stream))
+        if rc != OK:
+            raise GlfError(rc, "glf_ctx_create(device=%d)" % device)
+        self._comm_keepalive = None
+
+    def close(self):
+        if self._ctx:
+            _lib.glf_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what=""):
+        if rc != OK:
+            raise GlfError(rc, (what + " " if what else "") + _lib.glf_ctx_last_error(self._ctx).decode())
+
+    def synchronize(self):
+        self._check(_lib.glf_ctx_synchronize(self._ctx))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(), C.c_size_t()
+        self._check(_lib.glf_ctx_device_info(self._ctx, name, C.c_size_t(256), C.byref(cus), C.byref(mem)))
+        return dict(name=name.value.decode(), num_cus=cus.value, total_mem=mem.value)
+
+    # -- collectives: torch.distributed on tensors aliasing the device buffers ------------
+    def set_comm_torch(self, group=None):
+        """Plug torch.distributed all-reduces (RCCL on GPU) into glf_comm."""
+        import torch.distributed as dist
+        torch = self.torch
+        size = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        if size == 1:
+            self._check(_lib.glf_ctx_set_comm(self._ctx, None))
+            return
+        dev = self.device
+
+        def as_tensor(ptr, count, dtype):
+            # zero-copy view of the library's device buffer
+            iface = {"shape": (count,), "typestr": "<f8" if dtype == torch.float64 else "<f4",
+                     "data": (ptr, False), "version": 2, "strides": None}
+
+            class _Holder:
+                __cuda_array_interface__ = iface
+            return torch.as_tensor(_Holder(), device=dev)
+
+        # RCCL reduces device buffers in place; a gloo group (CPU rehearsal of the N > 1 path,
+        # or several ranks sharing one GPU in tests) is staged through host memory.
+        on_device = dist.get_backend(group) == "nccl"
+
+        def allreduce(ptr, count, dtype):
+            t = as_tensor(ptr, count, dtype)
+            if on_device:
+                dist.all_reduce(t, group=group)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, group=group)
+                t.copy_(h)
+
+        def ar32(user, ptr, count):
+            try:
+                allreduce(ptr, count, torch.float32)
+                return 0
+            except Exception as exc:  # noqa: BLE001 - status code crosses the C boundary
+                print("glf allreduce_sum_f32 failed:", exc)
+                return 1
+
+        def ar64(user, ptr, count):
+            try:
+                allreduce(ptr, count, torch.float64)
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print("glf allreduce_sum_f64 failed:", exc)
+                return 1
+
+        comm = Comm(rank, size, ALLREDUCE_F32(ar32), ALLREDUCE_F64(ar64), None)
+        self._comm_keepalive = comm
+        self._check(_lib.glf_ctx_set_comm(self._ctx, C.byref(comm)))
+
+    # -- helpers ---------------------------------------------------------------------------
+    def to_device(self, img):
+        t = self.torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(self.device)
+        return t
+
+    def mat_to_numpy(self, mat):
+        """Dense / diagonal glf_mat -> numpy (rows x cols), padding stripped."""
+        if mat.kind == MAT_DIAG:
+            out = np.empty(mat.rows, dtype=np.float32)
+            self._check(_lib.glf_memcpy_d2h(self._ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(mat.data),
+                                            C.c_size_t(out.nbytes)))
+            return out
+        assert mat.kind == MAT_DENSE
+        full = np.empty((mat.rows, mat.ld), dtype=np.float32)
+        self._check(_lib.glf_memcpy_d2h(self._ctx, full.ctypes.data_as(C.c_void_p), C.c_void_p(mat.data),
+                                        C.c_size_t(full.nbytes)))
+        return full[:, :mat.cols].copy()
+
+    def degree_of(self, K_B):
+        out = np.empty(K_B.p, dtype=np.float64)
+        self._check(_lib.glf_memcpy_d2h(self._ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(K_B.degree),
+                                        C.c_size_t(out.nbytes)))
+        return out
+
+    def dense_from_numpy(self, arr, ld=None, row_order=ROWS_NA):
+        """numpy (rows x cols) -> dense glf_mat with ld rounded up to a power of two >= 32."""
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        rows, cols = arr.shape
+        if ld is None:
+            ld = 32
+            while ld < cols:
+                ld *= 2
+        mat = Mat()
+        self._check(_lib.glf_mat_create_dense(self._ctx, C.byref(mat), C.c_int64(rows), C.c_int64(cols), C.c_int64(ld)))
+        full = np.zeros((rows, ld), dtype=np.float32)
+        full[:, :cols] = arr
+        self._check(_lib.glf_memcpy_h2d(self._ctx, C.c_void_p(mat.data), full.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(full.nbytes)))
+        mat.row_order = row_order
+        return mat
+
+    def diag_from_numpy(self, vec):
+        vec = np.ascontiguousarray(vec, dtype=np.float32)
+        mat = Mat()
+        self._check(_lib.glf_mat_create_diag(self._ctx, C.byref(mat), C.c_int64(vec.size)))
+        self._check(_lib.glf_memcpy_h2d(self._ctx, C.c_void_p(mat.data), vec.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(vec.nbytes)))
+        return mat
+
+    def destroy(self, *mats):
+        for m in mats:
+            _lib.glf_mat_destroy(self._ctx, C.byref(m))
+
+    # -- stages (names as in hpc/*.h) -------------------------------------------------------
+    def ComputeAffinityMatrices(self, d_img, sample_indices, want_KA=True, kernel=KERNEL_BILATERAL,
+                                h_loc=40.0, h_val=30.0):
+        assert d_img.dtype == self.torch.uint8 and d_img.is_cuda and d_img.dim() == 2 and d_img.is_contiguous()
+        h, w = d_img.shape
+        idx = np.ascontiguousarray(sample_indices, dtype=np.uint32)
+        K_A, K_B = Mat(), Mat()
+        self._check(_lib.glf_ComputeAffinityMatrices(
+            self._ctx, C.byref(K_A) if want_KA else None, C.byref(K_B), C.c_void_p(d_img.data_ptr()), C.c_int(w),
+            C.c_int(h), C.c_uint(idx.size), idx.ctypes.data_as(C.c_void_p), C.c_int(kernel), C.c_float(h_loc),
+            C.c_float(h_val)), "ComputeAffinityMatrices")
+        K_B._img_keepalive = d_img
+        return (K_A if want_KA else None), K_B
+
+    def ComputeLaplacianMatrix(self, K_A, K_B):
+        L_A, L_B = Mat(), Mat()
+        alpha = C.c_double()
+        self._check(_lib.glf_ComputeLaplacianMatrix(self._ctx, C.byref(L_A), C.byref(L_B),
+                                                    C.byref(K_A) if K_A is not None else None, C.byref(K_B),
+                                                    C.byref(alpha)), "ComputeLaplacianMatrix")
+        return L_A, L_B, alpha.value
+
+    def InversePowerIteration(self, A, m, optiGramSchmidt=1, epsilon=0.1, inner_rtol=1e-5, max_outer=100000,
+                              X0=None, allow_noconv=False):
+        vecs, vals = Mat(), Mat()
+        st = EigStats()
+        x0p = None
+        if X0 is not None:
+            X0 = np.ascontiguousarray(X0, dtype=np.float64)
+            assert X0.shape == (m, A.rows)
+            x0p = X0.ctypes.data_as(C.c_void_p)
+        rc = _lib.glf_InversePowerIteration(self._ctx, C.byref(A), C.c_uint(m), C.byref(vecs), C.byref(vals),
+                                            C.c_int(optiGramSchmidt), C.c_double(epsilon), C.c_double(inner_rtol),
+                                            C.c_int(max_outer), x0p, C.byref(st))
+        if not (allow_noconv and rc == ERR_NOCONV):
+            self._check(rc, "InversePowerIteration")
+        return vecs, vals, dict(outer_its=st.outer_its, inner_its_total=st.inner_its_total, residual=st.residual)
+
+    def OrthonormaliseVecs(self, X):
+        norms = np.empty(X.cols, dtype=np.float64)
+        self._check(_lib.glf_OrthonormaliseVecs(self._ctx, C.byref(X), norms.ctypes.data_as(C.c_void_p)))
+        return norms
+
+    def NormaliseVecs(self, X):
+        norms = np.empty(X.cols, dtype=np.float64)
+        self._check(_lib.glf_NormaliseVecs(self._ctx, C.byref(X), norms.ctypes.data_as(C.c_void_p)))
+        return norms
+
+    def InverseDiagMat(self, x):
+        inv = Mat()
+        self._check(_lib.glf_InverseDiagMat(self._ctx, C.byref(x), C.byref(inv)))
+        return inv
+
+    def Nystroem(self, B, phi_A, Pi_A_Inv):
+        phi = Mat()
+        self._check(_lib.glf_Nystroem(self._ctx, C.byref(B), C.byref(phi_A), C.byref(Pi_A_Inv), C.byref(phi)), "Nystroem")
+        return phi
+
+    def Permutation(self, mat, sample_indices):
+        idx = np.ascontiguousarray(sample_indices, dtype=np.uint32)
+        out = Mat()
+        self._check(_lib.glf_Permutation(self._ctx, C.byref(mat), idx.ctypes.data_as(C.c_void_p), C.c_uint(idx.size),
+                                         C.byref(out)), "Permutation")
+        return out
+
+    def ComputeResultFromLaplacian(self, d_img, phi, Pi, gain=3.0, want_float=True):
+        torch = self.torch
+        h, w = d_img.shape
+        out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+        zf = torch.empty((h, w), dtype=torch.float32, device=self.device) if want_float else None
+        self._check(_lib.glf_ComputeResultFromLaplacian(
+            self._ctx, C.c_void_p(d_img.data_ptr()), C.byref(phi), C.byref(Pi), C.c_uint(w), C.c_uint(h),
+            C.c_float(gain), C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None),
+            "ComputeResultFromLaplacian")
+        return out, zf
+
+    def image_processing(self, d_img, opt=None, want_float=False, out=None):
+        """Whole approximate path (hpc/image_processing.c:183-277) on a device image tensor."""
+        torch = self.torch
+        assert d_img.dtype == torch.uint8 and d_img.is_cuda and d_img.dim() == 2 and d_img.is_contiguous()
+        h, w = d_img.shape
+        opt = opt or default_options()
+        if out is None:
+            out = torch.zeros((h, w), dtype=torch.uint8, device=self.device)
+        zf = torch.zeros((h, w), dtype=torch.float32, device=self.device) if want_float else None
+        st = Stats()
+        lam = np.zeros(256, dtype=np.float64)
+        rc = _lib.glf_image_processing(self._ctx, C.byref(opt), C.c_void_p(d_img.data_ptr()), C.c_int(w), C.c_int(h),
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None,
+                                       lam.ctypes.data_as(C.c_void_p), C.byref(st))
+        self._check(rc, "image_processing")
+        info = dict(p=st.p, m=st.m, alpha=st.alpha, outer_its=st.eig.outer_its,
+                    inner_its_total=st.eig.inner_its_total, residual=st.eig.residual,
+                    ms_affinity=st.ms_affinity, ms_laplacian=st.ms_laplacian, ms_eigen=st.ms_eigen,
+                    ms_nystroem=st.ms_nystroem, ms_filter=st.ms_filter, ms_total=st.ms_total,
+                    nystroem_kernel_ms=st.nystroem_kernel_ms, nystroem_launches=st.nystroem_launches,
+                    row0=st.row0, row1=st.row1, eigvals=lam[:st.m].copy())
+        return out, zf, info

@@ -1,0 +1,253 @@
+/*
+ * image_processing.c -- host shell of the MI355X-native graph-Laplacian filter.
+ * Same entry point, flags, stage order, log lines and output files as the
+ * reference's hpc/image_processing.c, with PETSc/SLEPc/MPI replaced by the HIP
+ * C-ABI (include/glf.h) through the stage mirror in stages.h.
+ *
+ *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
+ *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
+ *
+ * The approximate path runs the tail the reference left commented out
+ * (hpc/image_processing.c:240-275) as its specification (survey quirk Q1).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "stages.h"
+
+static double wtime(void) /* MPI_Wtime */
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---- option database (PetscOptionsGet*, hpc/image_processing.c:82-154) ---------- */
+static int g_argc;
+static char **g_argv;
+
+static const char *opt_value(const char *name)
+{
+    for (int i = 1; i + 1 < g_argc; ++i)
+        if (strcmp(g_argv[i], name) == 0) return g_argv[i + 1];
+    return NULL;
+}
+static int opt_has(const char *name)
+{
+    for (int i = 1; i < g_argc; ++i)
+        if (strcmp(g_argv[i], name) == 0) return 1;
+    return 0;
+}
+
+static void GetFilePath(char *filename, size_t len) /* :82-94 */
+{
+    const char *v = opt_value("-f");
+    if (!v) {
+        fprintf(stderr, "No filename found (option -f)\n");
+        exit(1);
+    }
+    snprintf(filename, len, "%s", v);
+}
+
+static unsigned GetNumberEigenvalues(unsigned sample_size) /* :96-108 */
+{
+    const char *v = opt_value("-num_eigvals");
+    long n = v ? strtol(v, NULL, 10) : -1;
+    if (!v || n < 0 || n >= (long)sample_size) {
+        n = (long)sample_size - 1;
+        fprintf(stderr, "Invalid or invalid number of eigenvalues found (option -num_eigvals), so using %ld\n", n);
+    }
+    return (unsigned)n;
+}
+
+static int GetOptiGramSchmidt(void) /* :128-140 */
+{
+    const char *v = opt_value("-opti_gs");
+    const long n = v ? strtol(v, NULL, 10) : 1;
+    return n < 1 ? 1 : (int)n;
+}
+
+static double GetInverseIterationEpsilon(void) /* :142-154 */
+{
+    const char *v = opt_value("-inv_it_epsilon");
+    return v ? strtod(v, NULL) : 0.1;
+}
+
+static unsigned GetRequestedSamples(unsigned width, unsigned height)
+{
+    const char *n = opt_value("-num_samples"), *f = opt_value("-sample_frac");
+    if (n) return (unsigned)strtoul(n, NULL, 10);
+    const double frac = f ? strtod(f, NULL) : 0.01; /* p = width*height*0.01, :187 */
+    return (unsigned)(width * height * frac);
+}
+
+static void free_rows(png_bytep *rows, int height)
+{
+    if (!rows) return;
+    for (int i = 0; i < height; ++i) free(rows[i]);
+    free(rows);
+}
+
+/* ApproximationComputation, hpc/image_processing.c:183-277, stage by stage */
+static png_bytep *ApproximationComputation(png_bytep *img_bytes, unsigned width, unsigned height)
+{
+    unsigned p = GetRequestedSamples(width, height);
+    unsigned *sample_indices = NULL;
+    Sampling((int)width, (int)height, &p, &sample_indices);
+    if (!sample_indices || p < 2) {
+        fprintf(stderr, "Sampling failed\n");
+        return NULL;
+    }
+    printf("Sample size: %d\n", p);
+    const unsigned m = GetNumberEigenvalues(p);
+
+    double t = wtime();
+    printf("Computing affinity matrices... ");
+    Mat K_A = NULL, K_B = NULL;
+    if (ComputeAffinityMatrices(&K_A, &K_B, img_bytes, (int)width, (int)height, p, sample_indices) != GLF_OK) goto fail;
+    printf("%fs\n", wtime() - t);
+
+    t = wtime();
+    printf("Computing Laplacian matrices... ");
+    Mat L_A = NULL, L_B = NULL;
+    if (ComputeLaplacianMatrix(&L_A, &L_B, K_A, K_B) != GLF_OK) goto fail;
+    printf("%fs\n", wtime() - t);
+    MatDestroy(&K_A); /* K_B's tables are shared with L_B: destroyed at the end */
+
+    t = wtime();
+    Mat eigvals = NULL, eigvecs_A = NULL;
+    printf("Computing %d smallest eigenvalues... ", m);
+    if (opt_has("-use_slepc")) {
+        fprintf(stderr, "-use_slepc: SLEPc is not part of this build; using the inverse subspace iteration\n");
+    }
+    const double epsilon = GetInverseIterationEpsilon();
+    printf("(epsilon: %g) ", epsilon);
+    if (InversePowerIteration(L_A, m, &eigvecs_A, &eigvals, GetOptiGramSchmidt(), epsilon) != GLF_OK) goto fail;
+    printf("%fs\n", wtime() - t);
+    printf("Inverse subspace iteration took %d outer iterations\n", LastEigStats()->outer_its);
+    WriteDiagMat(eigvals, "results/eigenvalues_laplacian.txt");
+    MatDestroy(&L_A);
+
+    Mat eigvals_inv = InverseDiagMat(eigvals); /* :240 */
+    t = wtime();
+    printf("Computing Nystr\xc3\xb6m approximation... ");
+    Mat eigvecs = Nystroem(L_B, eigvecs_A, eigvals_inv, width * height, p, m); /* :245 */
+    if (!eigvecs) goto fail;
+    printf("%fs\n", wtime() - t);
+    MatDestroy(&eigvecs_A);
+    MatDestroy(&eigvals_inv);
+    MatDestroy(&L_B);
+
+    Mat eigvecs_perm = Permutation(eigvecs, sample_indices, p); /* :251 */
+    MatDestroy(&eigvecs);
+    eigvecs = eigvecs_perm;
+    if (!eigvecs) goto fail;
+
+    Mat f_eigvals = MatPow(eigvals, 6); /* :263, a no-op in the reference */
+    MatDestroy(&eigvals);
+
+    t = wtime();
+    printf("Computing output image... ");
+    png_bytep *output_img = ComputeResultFromLaplacian(img_bytes, eigvecs, f_eigvals, width, height); /* :269 */
+    printf("%fs\n", wtime() - t);
+    MatDestroy(&eigvecs);
+    MatDestroy(&f_eigvals);
+    MatDestroy(&K_B);
+    free(sample_indices);
+    return output_img;
+fail:
+    fprintf(stderr, "\nstage failed: %s\n", glf_ctx_last_error(glf_world()));
+    free(sample_indices);
+    return NULL;
+}
+
+/* Same path through the single fused entry point (no stage materialisation:
+ * Phi is written in raster order directly and K_A is never stored). */
+static png_bytep *FusedComputation(png_bytep *img_bytes, unsigned width, unsigned height)
+{
+    glf_ctx *ctx = glf_world();
+    glf_options opt;
+    glf_options_default(&opt);
+    opt.num_samples = GetRequestedSamples(width, height);
+    const char *v = opt_value("-num_eigvals");
+    opt.num_eigvals = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
+    opt.opti_gs = GetOptiGramSchmidt();
+    opt.epsilon = GetInverseIterationEpsilon();
+    const size_t n = (size_t)width * height;
+    void *d_img = NULL, *d_out = NULL;
+    uint8_t *flat = (uint8_t *)malloc(n);
+    png_bytep *rows = NULL;
+    if (!flat || glf_malloc(ctx, &d_img, n) != GLF_OK || glf_malloc(ctx, &d_out, n) != GLF_OK) goto out;
+    for (unsigned r = 0; r < height; ++r) memcpy(flat + (size_t)r * width, img_bytes[r], width);
+    if (glf_memcpy_h2d(ctx, d_img, flat, n) != GLF_OK) goto out;
+    glf_stats st;
+    const int rc = glf_image_processing(ctx, &opt, (const uint8_t *)d_img, (int)width, (int)height, (uint8_t *)d_out, NULL, NULL, &st);
+    if (rc != GLF_OK) {
+        fprintf(stderr, "glf_image_processing: %s (%s)\n", glf_strerror(rc), glf_ctx_last_error(ctx));
+        goto out;
+    }
+    printf("Sample size: %d\n", st.p);
+    printf("Computing affinity matrices... %fs\n", st.ms_affinity * 1e-3);
+    printf("Computing Laplacian matrices... %fs\n", st.ms_laplacian * 1e-3);
+    printf("Computing %d smallest eigenvalues... (epsilon: %g) %fs\n", st.m, opt.epsilon, st.ms_eigen * 1e-3);
+    printf("Inverse subspace iteration took %d outer iterations\n", st.eig.outer_its);
+    printf("Computing Nystr\xc3\xb6m approximation... %fs\n", st.ms_nystroem * 1e-3);
+    printf("Computing output image... %fs\n", st.ms_filter * 1e-3);
+    if (glf_memcpy_d2h(ctx, flat, d_out, n) != GLF_OK) goto out;
+    rows = (png_bytep *)malloc(sizeof(png_bytep) * height);
+    for (unsigned r = 0; rows && r < height; ++r) {
+        rows[r] = (png_bytep)malloc(width);
+        memcpy(rows[r], flat + (size_t)r * width, width);
+    }
+out:
+    free(flat);
+    if (d_img) glf_free(ctx, d_img);
+    if (d_out) glf_free(ctx, d_out);
+    return rows;
+}
+
+int main(int argc, char **argv)
+{
+    g_argc = argc;
+    g_argv = argv;
+    char filename[4096];
+    const char *dev = opt_value("-device");
+    if (InitProgram(dev ? atoi(dev) : 0) != GLF_OK) return 2; /* :284 */
+    const double start_time = wtime();
+    printf("Running with %d processes\n", 1); /* :286 */
+    GetFilePath(filename, sizeof(filename));
+
+    int width = 0, height = 0;
+    png_bytep *img_bytes = NULL, *output_img = NULL;
+    if (read_png(filename, &img_bytes, &width, &height) != 0) { /* ReadAndBcastImage :291; status checked here */
+        fprintf(stderr, "Could not read %s as an 8-bit gray / RGB / RGBA PNG\n", filename);
+        FinalizeProgram();
+        return 1;
+    }
+    printf("Read image %s of size %dx%d => %d pixels\n", filename, width, height, width * height);
+
+    int status = 0;
+    if (opt_has("-no_approx")) { /* :294-297 */
+        fprintf(stderr, "-no_approx (full N x N matrices) is not part of this build (SURVEY 8f, next row f2)\n");
+        status = 3;
+    } else if (opt_has("-fused")) {
+        output_img = FusedComputation(img_bytes, (unsigned)width, (unsigned)height);
+    } else {
+        output_img = ApproximationComputation(img_bytes, (unsigned)width, (unsigned)height); /* :300 */
+    }
+
+    if (write_png("results/input.png", img_bytes, (unsigned)width, (unsigned)height) != 0) status = status ? status : 4; /* :306 */
+    if (output_img) {
+        if (write_png("results/output.png", output_img, (unsigned)width, (unsigned)height) != 0) status = status ? status : 4; /* :309 */
+    } else if (!status) {
+        status = 5;
+    }
+    printf("Total computation time: %fs\n", wtime() - start_time); /* :314 */
+
+    free_rows(img_bytes, height);
+    free_rows(output_img, height);
+    FinalizeProgram();
+    return status;
+}

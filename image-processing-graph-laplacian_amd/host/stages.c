@@ -1,0 +1,194 @@
+/*
+ * stages.c -- host-side mirror of the reference's stage functions over the C-ABI
+ * (see stages.h). Each function cites the reference code it stands for.
+ */
+#include "stages.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static glf_ctx *g_world = NULL;
+static glf_eig_stats g_eig_stats;
+static uint8_t *g_dimg = NULL; /* device copy of the image, uploaded once per run */
+static size_t g_dimg_bytes = 0;
+
+glf_ctx *glf_world(void) { return g_world; }
+const glf_eig_stats *LastEigStats(void) { return &g_eig_stats; }
+
+int InitProgram(int device)
+{
+    if (g_world) return 0;
+    const int rc = glf_ctx_create(&g_world, device, NULL);
+    if (rc != GLF_OK) fprintf(stderr, "glf_ctx_create failed: %s\n", glf_strerror(rc));
+    return rc;
+}
+
+void FinalizeProgram(void)
+{
+    if (!g_world) return;
+    if (g_dimg) glf_free(g_world, g_dimg);
+    g_dimg = NULL;
+    glf_ctx_destroy(g_world);
+    g_world = NULL;
+}
+
+static Mat new_mat(void) { return (Mat)calloc(1, sizeof(glf_mat)); }
+
+void MatDestroy(Mat *m)
+{
+    if (!m || !*m) return;
+    glf_mat_destroy(g_world, *m);
+    free(*m);
+    *m = NULL;
+}
+
+int read_png(const char *filename, png_bytep **row_pointers, int *width, int *height)
+{
+    return glf_read_png(filename, row_pointers, width, height);
+}
+
+int write_png(const char *filename, png_bytep *img_bytes, unsigned int width, unsigned int height)
+{
+    return glf_write_png(filename, img_bytes, width, height);
+}
+
+void Sampling(int width, int height, unsigned int *sample_size, unsigned int **sample_indices)
+{
+    if (glf_Sampling(width, height, sample_size, sample_indices) != GLF_OK) {
+        *sample_size = 0;
+        *sample_indices = NULL;
+    }
+}
+
+/* png_bytep* rows -> one flat device buffer (the reference broadcasts the rows to
+ * every rank instead, hpc/image_processing.c:45-76) */
+static const uint8_t *upload_image(const png_bytep *img_bytes, int width, int height)
+{
+    const size_t n = (size_t)width * height;
+    if (g_dimg && g_dimg_bytes != n) {
+        glf_free(g_world, g_dimg);
+        g_dimg = NULL;
+    }
+    if (!g_dimg) {
+        void *d = NULL;
+        if (glf_malloc(g_world, &d, n) != GLF_OK) return NULL;
+        g_dimg = (uint8_t *)d;
+        g_dimg_bytes = n;
+    }
+    uint8_t *flat = (uint8_t *)malloc(n);
+    if (!flat) return NULL;
+    for (int r = 0; r < height; ++r) memcpy(flat + (size_t)r * width, img_bytes[r], (size_t)width);
+    const int rc = glf_memcpy_h2d(g_world, g_dimg, flat, n);
+    free(flat);
+    return rc == GLF_OK ? g_dimg : NULL;
+}
+
+int ComputeAffinityMatrices(Mat *K_A, Mat *K_B, const png_bytep *img_bytes, int width, int height,
+                            unsigned int sample_size, const unsigned int *sample_indices)
+{
+    const uint8_t *d_img = upload_image(img_bytes, width, height);
+    if (!d_img) return GLF_ERR_NOMEM;
+    *K_A = new_mat();
+    *K_B = new_mat();
+    /* bilateral, h_loc = 40, h_val = 30: hpc/affinity.c:117-121 */
+    return glf_ComputeAffinityMatrices(g_world, *K_A, *K_B, d_img, width, height, sample_size, sample_indices,
+                                       GLF_KERNEL_BILATERAL, 40.0f, 30.0f);
+}
+
+int ComputeLaplacianMatrix(Mat *L_A, Mat *L_B, Mat K_A, Mat K_B)
+{
+    *L_A = new_mat();
+    *L_B = new_mat();
+    return glf_ComputeLaplacianMatrix(g_world, *L_A, *L_B, K_A, K_B, NULL);
+}
+
+int InversePowerIteration(const Mat A, unsigned int m, Mat *eigenvectors, Mat *eigenvalues,
+                          int optiGramSchmidt, double epsilon)
+{
+    *eigenvectors = new_mat();
+    *eigenvalues = new_mat();
+    /* X0 seed 1, inner rtol 1e-5 (PETSc KSP default), no outer cap in the reference */
+    return glf_InversePowerIteration(g_world, A, m, *eigenvectors, *eigenvalues, optiGramSchmidt, epsilon, 1e-5,
+                                     100000, NULL, &g_eig_stats);
+}
+
+Mat InverseDiagMat(Mat x)
+{
+    Mat y = new_mat();
+    if (glf_InverseDiagMat(g_world, x, y) != GLF_OK) MatDestroy(&y);
+    return y;
+}
+
+/* hpc/utils.c:705-729: the reference computes pow(value, x) and discards it
+ * (:721), so the returned matrix equals A. Reproduced (survey quirk Q3). */
+Mat MatPow(Mat A, double x)
+{
+    (void)x;
+    Mat B = new_mat();
+    if (glf_mat_create_diag(g_world, B, A->rows) != GLF_OK) { MatDestroy(&B); return NULL; }
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)A->rows);
+    glf_memcpy_d2h(g_world, tmp, A->data, sizeof(float) * (size_t)A->rows);
+    glf_memcpy_h2d(g_world, B->data, tmp, sizeof(float) * (size_t)A->rows);
+    free(tmp);
+    return B;
+}
+
+Mat Nystroem(Mat B, Mat phi_A, Mat Pi_A_Inv, unsigned int N, unsigned int n, unsigned int p)
+{
+    (void)N; (void)n; (void)p; /* carried by the descriptors */
+    Mat phi = new_mat();
+    if (glf_Nystroem(g_world, B, phi_A, Pi_A_Inv, phi) != GLF_OK) {
+        fprintf(stderr, "Nystroem: %s\n", glf_ctx_last_error(g_world));
+        MatDestroy(&phi);
+    }
+    return phi;
+}
+
+Mat Permutation(Mat m, const unsigned int *sample_indices, unsigned int num_sample_indices)
+{
+    Mat out = new_mat();
+    if (glf_Permutation(g_world, m, sample_indices, num_sample_indices, out) != GLF_OK) MatDestroy(&out);
+    return out;
+}
+
+png_bytep *ComputeResultFromLaplacian(const png_bytep *img_bytes, Mat phi, Mat Pi, unsigned int width,
+                                      unsigned int height)
+{
+    const uint8_t *d_img = upload_image(img_bytes, (int)width, (int)height);
+    const size_t n = (size_t)width * height;
+    void *d_out = NULL;
+    if (!d_img || glf_malloc(g_world, &d_out, n) != GLF_OK) return NULL;
+    png_bytep *rows = NULL;
+    /* gain 3.0: hpc/display.c:73 */
+    if (glf_ComputeResultFromLaplacian(g_world, d_img, phi, Pi, width, height, 3.0f, (uint8_t *)d_out, NULL) == GLF_OK) {
+        uint8_t *flat = (uint8_t *)malloc(n);
+        if (flat && glf_memcpy_d2h(g_world, flat, d_out, n) == GLF_OK) {
+            rows = (png_bytep *)malloc(sizeof(png_bytep) * height); /* OneColMat2pngbytes, hpc/utils.c:509-513 */
+            for (unsigned int r = 0; rows && r < height; ++r) {
+                rows[r] = (png_bytep)malloc(width);
+                memcpy(rows[r], flat + (size_t)r * width, width);
+            }
+        }
+        free(flat);
+    } else {
+        fprintf(stderr, "ComputeResultFromLaplacian: %s\n", glf_ctx_last_error(g_world));
+    }
+    glf_free(g_world, d_out);
+    return rows;
+}
+
+/* WriteDiagMat (hpc/display.c:51-56): one value per line (PETSc's ASCII viewer
+ * header is third-party formatting and is not reproduced). */
+int WriteDiagMat(Mat x, const char *filename)
+{
+    const size_t n = (size_t)x->rows;
+    float *h = (float *)malloc(sizeof(float) * n);
+    if (!h || glf_memcpy_d2h(g_world, h, x->data, sizeof(float) * n) != GLF_OK) { free(h); return -1; }
+    FILE *f = fopen(filename, "w");
+    if (!f) { free(h); return -1; }
+    for (size_t i = 0; i < n; ++i) fprintf(f, "%.9g\n", (double)h[i]);
+    fclose(f);
+    free(h);
+    return 0;
+}

@@ -4,7 +4,7 @@
  * Drop-in boundary for the approximate path of the reference program
  * hpc/image_processing (David-Wobrock/image-processing-graph-laplacian).
  * The reference has no FFI; its boundary is the per-stage C prototypes in
- * hpc/*.h, all of which take PETSc Mat/Vec. Here Mat/Vec become flat HIP
+ * the hpc/ headers, all of which take PETSc Mat/Vec. Here Mat/Vec become flat HIP
  * device buffers described by the plain struct glf_mat; every entry point is
  * extern "C", takes plain pointers and sizes, and returns an int status
  * (0 = GLF_OK) instead of void. Each declaration cites the reference
@@ -130,7 +130,7 @@ int glf_random_vectors(double *X0, unsigned p, unsigned m, uint64_t seed);
  * the reference. out: height*width bytes. */
 int glf_synth_image(uint8_t *out, int width, int height, uint64_t seed);
 
-/* ---- device stages (mirror hpc/*.h, "glf_" prefixed) -------------------------- */
+/* ---- device stages (mirror the hpc/ headers, "glf_" prefixed) -------------------------- */
 
 /* void ComputeAffinityMatrices(Mat* K_A, Mat* K_B, const png_bytep* img, int w, int h,
  *                              unsigned p, const unsigned* idx)   hpc/affinity.h:5, hpc/affinity.c:129-262

@@ -1,0 +1,350 @@
+"""Parity of the HIP path (through the C-ABI, libglf.so) against the fp64 CPU
+oracle on the same inputs, stage by stage and end to end, plus the committed
+golden vectors of the reference's Python PoC. Needs an MI355X: -m gpu.
+
+Tolerances (fp32 device arithmetic vs fp64 oracle; north_star asks for a stated
+fp64 -> fp32 PSNR tolerance):
+  kernel entries      rel 3e-6   (one v_exp_f32 + 5 roundings)
+  degree D_A, alpha   rel 2e-6   (f32 within an image row, f64 across)
+  L_A                 abs 3e-6 * max|L_A|
+  eigenvalues         abs 2e-4   (same X0, same stopping rule)
+  Phi                 abs 2e-4 * max|Phi|
+  z (float)           abs 2e-2 grey levels; u8 output: PSNR >= 50 dB and
+                      |delta| <= 1 grey level on >= 99 % of pixels
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import glf  # noqa: E402  (fails loudly when libglf.so is missing)
+import oracle as orc  # noqa: E402
+from conftest import psnr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    c = glf.Context(0)
+    yield c
+    c.close()
+
+
+def _lapack_pairs(LA, m):
+    w, V = np.linalg.eigh(LA)
+    return np.ascontiguousarray(V[:, :m].T), w[:m]
+
+
+def _images(golden, png):
+    return {
+        "syn32": (golden("syn32.npz")["img"], 10),
+        "test": (png("test.png"), 100),
+        "ragged": (glf.synth_image(53, 37, seed=3), 20),
+        "cat50": (png("cat_small.png"), 50),
+    }
+
+
+@pytest.mark.parametrize("name", ["syn32", "test", "ragged", "cat50"])
+def test_affinity_degree_laplacian(ctx, golden, png, name):
+    img, p_req = _images(golden, png)[name]
+    h, w = img.shape
+    idx = glf.Sampling(w, h, p_req)
+    d_img = ctx.to_device(img)
+    K_A, K_B = ctx.ComputeAffinityMatrices(d_img, idx)
+    KA_ref, _ = orc.affinity(img, idx, want_KB=False)
+    np.testing.assert_allclose(ctx.mat_to_numpy(K_A), KA_ref, rtol=3e-6, atol=1e-30)
+    D_ref = orc.degree(img, idx)
+    np.testing.assert_allclose(ctx.degree_of(K_B), D_ref, rtol=2e-6)
+    assert (K_B.kind, K_B.rows, K_B.cols, K_B.scale) == (glf.MAT_KERNEL_B, idx.size, h * w - idx.size, 1.0)
+    L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(K_A, K_B)
+    LA_ref, alpha_ref = orc.laplacian(KA_ref, D_ref)
+    assert alpha == pytest.approx(alpha_ref, rel=2e-6)
+    np.testing.assert_allclose(ctx.mat_to_numpy(L_A), LA_ref, rtol=0, atol=3e-6 * np.abs(LA_ref).max())
+    assert L_B.scale == pytest.approx(-alpha_ref, rel=1e-5)
+    # same L_A when K_A is not materialised
+    L_A2, _, _ = ctx.ComputeLaplacianMatrix(None, K_B)
+    np.testing.assert_array_equal(ctx.mat_to_numpy(L_A2), ctx.mat_to_numpy(L_A))
+    ctx.destroy(K_A, L_A, L_A2, K_B)
+
+
+@pytest.mark.parametrize("kernel,ok", [(glf.KERNEL_PHOTOMETRIC, orc.PHOTOMETRIC), (glf.KERNEL_SPATIAL, orc.SPATIAL)])
+def test_other_kernels_against_golden(ctx, golden, kernel, ok):
+    g = golden("syn32.npz")
+    name = "photometric" if kernel == glf.KERNEL_PHOTOMETRIC else "spatial"
+    d_img = ctx.to_device(g["img"])
+    K_A, K_B = ctx.ComputeAffinityMatrices(d_img, g["idx"], kernel=kernel, h_loc=10.0, h_val=10.0)
+    np.testing.assert_allclose(ctx.mat_to_numpy(K_A), g["K_A_" + name], rtol=5e-6, atol=1e-30)
+    D_ref = g["K_A_" + name].sum(1) + g["K_B_" + name].sum(1)
+    np.testing.assert_allclose(ctx.degree_of(K_B), D_ref, rtol=3e-6)
+    ctx.destroy(K_A, K_B)
+
+
+def test_stage_goldens_from_python_poc(ctx, golden, png):
+    """K_A, D_A, alpha of the reference's PoC (tests/golden) reproduced by the HIP path."""
+    for npz, img, p_req in (("syn32.npz", golden("syn32.npz")["img"], 10), ("test_png.npz", png("test.png"), 100),
+                            ("cat50.npz", png("cat_small.png"), 50)):
+        g = golden(npz)
+        h, w = img.shape
+        idx = glf.Sampling(w, h, p_req)
+        np.testing.assert_array_equal(idx, g["idx"])
+        K_A, K_B = ctx.ComputeAffinityMatrices(ctx.to_device(img), idx)
+        np.testing.assert_allclose(ctx.mat_to_numpy(K_A), g["K_A"], rtol=3e-6, atol=1e-30)
+        np.testing.assert_allclose(ctx.degree_of(K_B), g["D_A"], rtol=2e-6)
+        L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(K_A, K_B)
+        assert alpha == pytest.approx(float(g["alpha"]), rel=2e-6)
+        ctx.destroy(K_A, L_A, K_B)
+
+
+@pytest.mark.parametrize("n,m", [(200, 12), (1000, 33), (2601, 64), (77, 5), (5000, 100)])
+def test_orthonormalise_and_normalise(ctx, n, m):
+    X = orc.random_vectors(n, m, 7)          # (m, n): one row per vector
+    Q_ref, norms_ref = orc.orthonormalise(X)
+    Xd = ctx.dense_from_numpy(X.T)           # device layout: n x m
+    norms = ctx.OrthonormaliseVecs(Xd)
+    Q = ctx.mat_to_numpy(Xd).T
+    np.testing.assert_allclose(norms, norms_ref, rtol=2e-5)
+    np.testing.assert_allclose(Q, Q_ref, rtol=0, atol=2e-4 * np.abs(Q_ref).max() * np.sqrt(m))
+    np.testing.assert_allclose(Q.dot(Q.T), np.eye(m), atol=5e-5 * m)
+    Y = ctx.dense_from_numpy((X * 3.0).T)
+    nn = ctx.NormaliseVecs(Y)
+    np.testing.assert_allclose(nn, 3.0 * np.linalg.norm(X, axis=1), rtol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(ctx.mat_to_numpy(Y), axis=0), 1.0, rtol=1e-6)
+    ctx.destroy(Xd, Y)
+
+
+@pytest.mark.parametrize("name,m,eps", [("syn32", 4, 1e-3), ("test", 16, 1e-2), ("test", 16, 0.1), ("cat50", 53, 0.1),
+                                         ("test", 99, 0.1)])
+def test_inverse_power_iteration_matches_oracle(ctx, golden, png, name, m, eps):
+    img, p_req = _images(golden, png)[name]
+    h, w = img.shape
+    idx = glf.Sampling(w, h, p_req)
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    LA, alpha = orc.laplacian(KA, orc.degree(img, idx))
+    p = idx.size
+    X0 = glf.random_vectors(p, m, 1)
+    vecs_ref, vals_ref, st_ref = orc.inverse_power_iteration(LA, m, X0, epsilon=eps, inner_rtol=1e-5)
+    A = ctx.dense_from_numpy(LA, ld=(p + 31) // 32 * 32)
+    vecs, vals, st = ctx.InversePowerIteration(A, m, epsilon=eps, inner_rtol=1e-5, X0=X0)
+    assert abs(st["outer_its"] - st_ref["outer_its"]) <= 1
+    assert st["residual"] <= eps
+    if st["outer_its"] == st_ref["outer_its"]:
+        np.testing.assert_allclose(ctx.mat_to_numpy(vals), vals_ref, atol=2e-4)
+        V = ctx.mat_to_numpy(vecs).T
+        np.testing.assert_allclose(V, vecs_ref, atol=2e-3)
+        np.testing.assert_allclose(np.linalg.norm(V, axis=1), 1.0, rtol=1e-5)
+    ctx.destroy(A, vecs, vals)
+
+
+def test_inverse_power_iteration_edge_cases(ctx, golden):
+    LA = golden("syn32.npz")["L_A"]
+    A = ctx.dense_from_numpy(LA, ld=32)
+    with pytest.raises(glf.GlfError):
+        ctx.InversePowerIteration(A, 0)
+    with pytest.raises(glf.GlfError):
+        ctx.InversePowerIteration(A, 9)  # m must be < p
+    # opti_gs > 1: eigenvalue estimates become mu^k (reference behaviour), still finite
+    X0 = glf.random_vectors(9, 4, 1)
+    _, vals3_ref, st_ref = orc.inverse_power_iteration(LA, 4, X0, opti_gs=3, epsilon=1e-3)
+    vecs, vals, st = ctx.InversePowerIteration(A, 4, optiGramSchmidt=3, epsilon=1e-3, X0=X0)
+    assert st["outer_its"] == st_ref["outer_its"]
+    np.testing.assert_allclose(ctx.mat_to_numpy(vals)[:2], vals3_ref[:2], rtol=5e-3)
+    ctx.destroy(vecs, vals)
+    # outer-iteration cap reports non-convergence instead of spinning
+    with pytest.raises(glf.GlfError) as ei:
+        ctx.InversePowerIteration(A, 4, epsilon=1e-30, max_outer=3, X0=X0)
+    assert ei.value.status == glf.ERR_NOCONV
+    ctx.destroy(A)
+
+
+@pytest.mark.parametrize("name,m", [("syn32", 4), ("syn32", 8), ("test", 16), ("ragged", 5), ("cat50", 53)])
+def test_nystroem_permutation_filter(ctx, golden, png, name, m):
+    img, p_req = _images(golden, png)[name]
+    h, w = img.shape
+    N = h * w
+    idx = glf.Sampling(w, h, p_req)
+    p = idx.size
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    LA, alpha = orc.laplacian(KA, orc.degree(img, idx))
+    vecs, vals = _lapack_pairs(LA, m)
+    phi_sf_ref = orc.nystroem(img, idx, alpha, vecs, vals)          # (m, N) sample-first
+    phi_ref = orc.permutation(phi_sf_ref, idx)
+    zf_ref, out_ref = orc.result_from_laplacian(img, phi_ref, vals, gain=3.0)
+
+    d_img = ctx.to_device(img)
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    L_A, L_B, alpha_gpu = ctx.ComputeLaplacianMatrix(None, K_B)
+    phi_A = ctx.dense_from_numpy(vecs.T)
+    Pi = ctx.diag_from_numpy(vals)
+    Pi_inv = ctx.InverseDiagMat(Pi)
+    np.testing.assert_allclose(ctx.mat_to_numpy(Pi_inv), 1.0 / vals, rtol=1e-6)
+    phi_sf = ctx.Nystroem(L_B, phi_A, Pi_inv)
+    assert (phi_sf.rows, phi_sf.cols, phi_sf.row_order) == (N, m, glf.ROWS_SAMPLE_FIRST)
+    scale = np.abs(phi_sf_ref).max()
+    got_sf = ctx.mat_to_numpy(phi_sf)
+    np.testing.assert_allclose(got_sf, phi_sf_ref.T, rtol=0, atol=2e-4 * scale)
+    np.testing.assert_array_equal(got_sf[:p], vecs.T.astype(np.float32))   # upper part = phi_A (hpc/nystroem.c:25-34)
+    with pytest.raises(glf.GlfError):
+        ctx.ComputeResultFromLaplacian(d_img, phi_sf, Pi)                   # must be permuted first
+    phi = ctx.Permutation(phi_sf, idx)
+    got = ctx.mat_to_numpy(phi)
+    np.testing.assert_array_equal(got, orc.permutation(got_sf.T.astype(np.float64), idx).T.astype(np.float32))
+    np.testing.assert_array_equal(got[idx], got_sf[:p])                     # hpc/utils.c:149-152
+    out, zf = ctx.ComputeResultFromLaplacian(d_img, phi, Pi, gain=3.0)
+    zf, out = zf.cpu().numpy(), out.cpu().numpy()
+    np.testing.assert_allclose(zf, zf_ref, rtol=0, atol=2e-2)
+    assert np.mean(np.abs(out.astype(int) - out_ref.astype(int)) <= 1) >= 0.999
+    assert psnr(out, out_ref) >= 50.0
+    ctx.destroy(L_A, phi_A, Pi, Pi_inv, phi_sf, phi, K_B)
+
+
+def test_filter_golden_from_python_poc(ctx, golden, png):
+    """z_c goldens (PoC stages + LAPACK pairs, tools/gen_golden.py): GPU L_A -> LAPACK
+    pairs -> GPU Nystroem/Permutation/filter must land on them."""
+    for npz, img, p_req, m, key in (("syn32.npz", golden("syn32.npz")["img"], 10, 4, "z_c_m4"),
+                                    ("test_png.npz", png("test.png"), 100, 16, "z_c_m16"),
+                                    ("cat50.npz", png("cat_small.png"), 50, 16, "z_c_m16")):
+        g = golden(npz)
+        h, w = img.shape
+        idx = glf.Sampling(w, h, p_req)
+        d_img = ctx.to_device(img)
+        _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+        L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(None, K_B)
+        vecs, vals = _lapack_pairs(ctx.mat_to_numpy(L_A).astype(np.float64), m)
+        phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
+        Pi_inv = ctx.InverseDiagMat(Pi)
+        phi = ctx.Permutation(ctx.Nystroem(L_B, phi_A, Pi_inv), idx)
+        out, zf = ctx.ComputeResultFromLaplacian(d_img, phi, Pi)
+        np.testing.assert_allclose(zf.cpu().numpy(), g[key], rtol=0, atol=3e-2)
+        ctx.destroy(L_A, phi_A, Pi, Pi_inv, phi, K_B)
+
+
+E2E = [
+    # name, num_samples, m, epsilon
+    ("syn32", 10, 4, 1e-3),
+    ("test", 100, 16, 0.1),
+    ("test", 100, 99, 0.1),       # m = p - 1, the reference default
+    ("ragged", 20, 5, 0.1),
+    ("cat50", 50, 53, 0.1),       # BASELINE config 1
+]
+
+
+@pytest.mark.parametrize("name,ns,m,eps", E2E)
+def test_image_processing_end_to_end(ctx, golden, png, name, ns, m, eps):
+    img, _ = _images(golden, png)[name]
+    zf_ref, out_ref, info_ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
+    opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    out, zf = out.cpu().numpy(), zf.cpu().numpy()
+    assert (info["p"], info["m"]) == (info_ref["p"], info_ref["m"])
+    assert info["alpha"] == pytest.approx(info_ref["alpha"], rel=2e-6)
+    assert abs(info["outer_its"] - info_ref["outer_its"]) <= 1
+    if info["outer_its"] == info_ref["outer_its"]:
+        np.testing.assert_allclose(info["eigvals"], info_ref["eigvals"], atol=2e-4)
+        rel_l2 = np.linalg.norm(zf - zf_ref) / np.linalg.norm(zf_ref)
+        assert rel_l2 <= 1e-4
+        assert psnr(out, out_ref) >= 50.0
+        assert np.mean(np.abs(out.astype(int) - out_ref.astype(int)) <= 1) >= 0.99
+
+
+def test_barbara_config2(ctx, golden, png):
+    """BASELINE config 2: 512x512 barbara, 1 % samples, fp32, one GPU."""
+    img = png("barbara.png")
+    g = golden("barbara.npz")
+    opt = glf.default_options(num_samples=2621, num_eigvals=64, epsilon=0.1)
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    assert info["p"] == 2601 and info["m"] == 64
+    assert info["alpha"] == pytest.approx(float(g["alpha"]), rel=2e-6)
+    zf_ref, out_ref, info_ref = orc.image_processing(img, 2621, 64, epsilon=0.1, inner_rtol=1e-5, seed=1)
+    assert abs(info["outer_its"] - info_ref["outer_its"]) <= 1
+    out, zf = out.cpu().numpy(), zf.cpu().numpy()
+    if info["outer_its"] == info_ref["outer_its"]:
+        assert np.linalg.norm(zf - zf_ref) / np.linalg.norm(zf_ref) <= 1e-4
+        assert psnr(out, out_ref) >= 50.0
+    # stage API on the same input lands on the PoC golden (LAPACK pairs)
+    idx = glf.Sampling(512, 512, 2621)
+    d_img = ctx.to_device(img)
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    np.testing.assert_allclose(ctx.degree_of(K_B), g["D_A"], rtol=2e-6)
+    L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(None, K_B)
+    w, V = np.linalg.eigh(ctx.mat_to_numpy(L_A).astype(np.float64))
+    np.testing.assert_allclose(w[:64], g["mu64"], rtol=0, atol=2e-5)
+    phi_A, Pi = ctx.dense_from_numpy(V[:, :64]), ctx.diag_from_numpy(w[:64])
+    Pi_inv = ctx.InverseDiagMat(Pi)
+    phi = ctx.Permutation(ctx.Nystroem(L_B, phi_A, Pi_inv), idx)
+    out2, zf2 = ctx.ComputeResultFromLaplacian(d_img, phi, Pi)
+    np.testing.assert_allclose(zf2.cpu().numpy()[::64], g["z_c_m64_rows"], rtol=0, atol=5e-2)
+    assert psnr(out2.cpu().numpy(), g["z_c_m64_u8"]) >= 50.0
+    ctx.destroy(L_A, phi_A, Pi, Pi_inv, phi, K_B)
+
+
+def test_size_independent_properties_1024(ctx):
+    """BASELINE config 5 tile size (1024x1024, 0.5 %): properties that need no oracle run."""
+    import torch
+    img = glf.synth_image(1024, 1024, seed=5)
+    d_img = ctx.to_device(img)
+    idx = glf.Sampling(1024, 1024, int(1024 * 1024 * 0.005))
+    assert idx.size == 5329
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    D = ctx.degree_of(K_B)
+    # row sums bounded by the spatial kernel's mass and by 1 (self affinity)
+    assert D.min() >= 1.0 and D.max() <= np.pi * 1600 * 1.0001
+    # oracle on a sub-sample of the samples (seconds): full-size degree parity
+    sub = idx[::211]
+    np.testing.assert_allclose(D[::211], orc.degree(img, sub), rtol=2e-6)
+    L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(None, K_B)
+    LA = ctx.mat_to_numpy(L_A)
+    np.testing.assert_array_equal(LA, LA.T)                          # symmetric
+    np.testing.assert_allclose(np.diag(LA), alpha * (D - 1.0), rtol=1e-6)
+    m = 32
+    vecs, vals, st = ctx.InversePowerIteration(L_A, m, epsilon=0.1)
+    assert st["residual"] <= 0.1 and st["outer_its"] >= 1
+    lam = ctx.mat_to_numpy(vals)
+    assert np.all(lam > 0) and np.all(np.isfinite(lam))
+    Pi_inv = ctx.InverseDiagMat(vals)
+    phi_sf = ctx.Nystroem(L_B, vecs, Pi_inv)
+    phi = ctx.Permutation(phi_sf, idx)
+    a, b = ctx.mat_to_numpy(phi_sf), ctx.mat_to_numpy(phi)
+    np.testing.assert_array_equal(b[idx], a[:idx.size])
+    rest = np.ones(1024 * 1024, dtype=bool)
+    rest[idx] = False
+    np.testing.assert_array_equal(b[rest], a[idx.size:])             # raster order of the remaining pixels
+    # a few non-sample pixel rows of Phi against the oracle's kernel (fp64)
+    V = ctx.mat_to_numpy(vecs).astype(np.float64)
+    prm = orc.default_params()
+    for px in (0, 123457, 1024 * 1024 - 1):
+        r, c, v = px // 1024, px % 1024, float(img.reshape(-1)[px])
+        k = np.array([orc.kernel_entry(prm, (float(i // 1024), float(i % 1024), float(img.reshape(-1)[i])), (r, c, v))
+                      for i in idx])
+        expect = (-alpha * k) @ (V / lam.astype(np.float64))
+        np.testing.assert_allclose(b[px], expect, rtol=0, atol=3e-4 * np.abs(expect).max() + 1e-7)
+    # fused path == stage path on the same eigen-solve settings
+    out_s, zf_s = ctx.ComputeResultFromLaplacian(d_img, phi, vals)
+    opt = glf.default_options(num_samples=int(1024 * 1024 * 0.005), num_eigvals=m, epsilon=0.1)
+    out_f, zf_f, info = ctx.image_processing(d_img, opt, want_float=True)
+    assert info["p"] == 5329 and info["outer_its"] == st["outer_its"]
+    assert torch.max(torch.abs(zf_f - zf_s)).item() <= 2e-2
+    assert psnr(out_f.cpu().numpy(), out_s.cpu().numpy()) >= 55.0
+    ctx.destroy(L_A, vecs, vals, Pi_inv, phi_sf, phi, K_B)
+
+
+def test_errors_are_loud(ctx):
+    import torch
+    img = glf.synth_image(64, 48, seed=1)
+    d_img = ctx.to_device(img)
+    with pytest.raises(glf.GlfError):       # descending indices
+        ctx.ComputeAffinityMatrices(d_img, np.array([50, 40, 30], dtype=np.uint32))
+    with pytest.raises(glf.GlfError):       # index out of range
+        ctx.ComputeAffinityMatrices(d_img, np.array([5, 64 * 48], dtype=np.uint32))
+    with pytest.raises(glf.GlfError):       # more samples than pixels
+        ctx.image_processing(d_img, glf.default_options(num_samples=10 ** 6))
+    with pytest.raises(glf.GlfError):       # > 256 eigenpairs unsupported (stated limit)
+        big = ctx.to_device(glf.synth_image(256, 256, seed=1))
+        ctx.image_processing(big, glf.default_options(num_samples=655, num_eigvals=300))
+    bad = glf.default_options()
+    bad.struct_size = 8
+    with pytest.raises(glf.GlfError):
+        ctx.image_processing(d_img, bad)
+    out, _, info = ctx.image_processing(d_img, glf.default_options(num_samples=12, num_eigvals=1000))
+    assert info["m"] == info["p"] - 1       # num_eigvals >= p -> p - 1 (hpc/image_processing.c:96-108)
+    assert out.dtype == torch.uint8
