@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the graph-Laplacian image filter hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One step = one whole pass of the approximate path (affinity/degree -> L_A ->
+inverse subspace iteration -> Nystroem contraction -> spectral filter) over one
+4096x4096 synthetic noisy image at 0.5 % sampling, m = 64 eigenpairs, with the
+image already resident in HBM and the filtered image left in HBM. With N > 1 the
+SAME image is split by pixel rows over the N ranks (strong scaling); the driver
+launches one rank per GPU through torch.distributed.run and the all-reduces
+(degree vector, Phi^T y) go over RCCL.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "image-processing-graph-laplacian_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import glf  # noqa: E402  (HIP path; raises if libglf.so is missing)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)" dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096, help="image is size x size (headline: 4096)")
+    ap.add_argument("--sample-frac", type=float, default=0.005)
+    ap.add_argument("--num-eigvals", type=int, default=64)
+    ap.add_argument("--epsilon", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(img, info, args):
+    """The fp64 CPU oracle (kind 'port': PETSc is not installable) timed on a bounded
+    slice of THIS workload and scaled: a band of pixel rows for the two K_B-bound stages, a band
+    of L_A rows for the eigen-solver's mat-vecs (iteration counts taken from the GPU run, which
+    follows the same algorithm), Gram-Schmidt once. 10-30 s of CPU work in total."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    h, w = img.shape
+    N = h * w
+    p, m = info["p"], info["m"]
+    idx = glf.Sampling(w, h, int(N * args.sample_frac))
+    cores = orc.num_threads()
+    # affinity/degree: rows band, all p samples
+    rows_deg = max(1, min(h, int(round(4e9 / (p * w)))))        # ~4e9 kernel evaluations
+    t0 = time.time()
+    orc.degree(img, idx, row0=h // 2, row1=h // 2 + rows_deg)
+    t_deg = (time.time() - t0) * h / rows_deg
+    # L_A rows band + block mat-vec on it
+    D = np.full(p, 1800.0)
+    band = max(32, min(p, int(2e9 / p)))                          # ~2e9 entries
+    t0 = time.time()
+    Arows = orc.laplacian_rows(img, idx, D, info["alpha"], 0, band)
+    t_lap = (time.time() - t0) * p / band
+    X = orc.random_vectors(p, m, 3)
+    t0 = time.time()
+    reps = 2
+    for _ in range(reps):
+        orc.matvec_rows(Arows, X)
+    t_mv = (time.time() - t0) / reps * p / band
+    del Arows
+    t0 = time.time()
+    orc.orthonormalise(X)
+    t_gs = time.time() - t0
+    n_mv = info["inner_its_total"] + info["outer_its"] + 1       # CG mat-vecs + one per residual
+    t_eig = n_mv * t_mv + (info["outer_its"] + 1) * t_gs
+    # Nystroem: rows band, all samples, m columns
+    rows_nys = max(1, min(h, int(round(6e8 / (p * w))) or 1))    # ~6e8 kernel evaluations x m FMAs
+    phiA = orc.random_vectors(p, m, 4)
+    t0 = time.time()
+    orc.nystroem_rows(img, idx, info["alpha"], phiA, np.linspace(0.1, 0.4, m), h // 2, h // 2 + rows_nys)
+    t_nys = (time.time() - t0) * h / rows_nys
+    total = t_deg + t_lap + t_eig + t_nys
+    return {
+        "value": round(N / total * 1e-6, 6), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+        "sample": ("fp64 oracle: degree on %d of %d pixel rows, L_A build + block mat-vec on %d of %d rows "
+                   "(x %d mat-vecs from the GPU run's iteration counts), Gram-Schmidt p x m once (x %d), "
+                   "Nystroem on %d of %d pixel rows; each stage scaled to the full image; filter stage "
+                   "(N m flops) neglected" % (rows_deg, h, band, p, n_mv, info["outer_its"] + 1, rows_nys, h)),
+        "seconds_est": {"affinity": round(t_deg, 1), "laplacian": round(t_lap, 1), "eigen": round(t_eig, 1),
+                        "nystroem": round(t_nys, 1), "total": round(total, 1)},
+    }
+
+
+def parity_check(ctx):
+    """PSNR of the HIP output against the fp64 oracle on BASELINE config 2 (barbara 512x512, 1 %,
+    m = 64): the 4096^2 oracle run would take about an hour of CPU, this one ~15 s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "barbara.png")))
+    opt = glf.default_options(num_samples=2621, num_eigvals=64, epsilon=0.1)
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    zf_ref, out_ref, ref = orc.image_processing(img, 2621, 64, epsilon=0.1, inner_rtol=1e-5, seed=1)
+    out, zf = out.cpu().numpy(), zf.cpu().numpy()
+    mse = float(np.mean((out.astype(np.float64) - out_ref) ** 2))
+    return {
+        "workload": "barbara.png 512x512, 1% samples (p=2601), m=64, eps=0.1 vs fp64 oracle",
+        "psnr_db": None if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2),
+        "identical_u8": mse == 0,
+        "rel_l2_float": float(np.linalg.norm(zf - zf_ref) / np.linalg.norm(zf_ref)),
+        "outer_its": [info["outer_its"], ref["outer_its"]],
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE (launch with torch.distributed.run)" % (args.gpus, world),
+              file=sys.stderr)
+
+    size = args.size
+    N = size * size
+    img = glf.synth_image(size, size, seed=0)      # byte-identical on every rank
+    ctx = glf.Context(local_rank)
+    if world > 1:
+        ctx.set_comm_torch()
+    d_img = ctx.to_device(img)
+    d_out = torch.zeros((size, size), dtype=torch.uint8, device=ctx.device)
+    opt = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals, epsilon=args.epsilon)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    info = None
+    for _ in range(args.warmup):
+        _, _, info = ctx.image_processing(d_img, opt, out=d_out)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
+    for _ in range(args.steps):
+        _, _, info = ctx.image_processing(d_img, opt, out=d_out)
+        kernel_ms.append(info["nystroem_kernel_ms"])
+        for k in stage_ms:
+            stage_ms[k] += info[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = N / (elapsed / args.steps) * 1e-6
+
+    if rank == 0:
+        p, m = info["p"], info["m"]
+        npix_local = (info["row1"] - info["row0"]) * size
+        n_samples_local = int(np.count_nonzero((glf.Sampling(size, size, int(N * args.sample_frac)) // size >= info["row0"]) &
+                                               (glf.Sampling(size, size, int(N * args.sample_frac)) // size < info["row1"])))
+        # algorithmic flops of ONE launch of the Nystroem contraction on this rank:
+        # 2 * (non-sample pixels) * p * m   (W_nys = 2 (N - p) p m)
+        flops = 2.0 * (npix_local - n_samples_local) * p * m
+        avg_ms = float(np.mean(kernel_ms))
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        line = {
+            "metric": "filtered Mpixels/sec @ 4K img, 0.5% samples",
+            "value": round(value, 4), "unit": "Mpixel/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g, "
+                                   "dense K_B (no spatial truncation)" % (size, size, args.sample_frac * 100, p, m, args.epsilon),
+                       "N": N, "p": p, "m": m, "epsilon": args.epsilon, "outer_its": info["outer_its"],
+                       "inner_its_total": info["inner_its_total"], "residual": round(info["residual"], 5),
+                       "sharding": "pixel rows / %d ranks" % n_gpus},
+            "stage_ms_rank0": {k[3:]: round(v / args.steps, 3) for k, v in stage_ms.items()},
+            "roofline": {"kernel": "k_nystroem (Nystroem contraction, f32 MFMA 32x32x2, K_B generated in registers)",
+                         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 3), "flops_per_launch": flops},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(img, info, args)
+        if n_gpus == 1 and not args.no_parity:
+            line["parity"] = parity_check(ctx)
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,11 @@ import ctypes as C
 import os
 
 import numpy as np
+# torch bundles its own libamdhip64.so.7; it must be loaded BEFORE libglf.so so that the
+# process ends up with one HIP runtime (the dynamic linker de-duplicates by SONAME and the
+# first one wins). Loading libglf.so first pairs torch with /opt/rocm's runtime and
+# hipGetDeviceCount then fails inside this library.
+import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglf.so")

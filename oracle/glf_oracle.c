@@ -643,3 +643,95 @@ int orc_entire_computation(const orc_params *prm, const uint8_t *img, int width,
     free(Ky); free(D);
     return 0;
 }
+
+/* ---------------------------------------------------------------- bounded-sample helpers
+ * Used by bench.py's cpu_baseline leg: the same stage arithmetic as above on a
+ * slice of the workload (a band of pixel rows / a band of L_A rows) so a 4096^2
+ * baseline can be timed in seconds and scaled. */
+
+/* Rows [i0,i1) of L_A = alpha (diag(D) - K_A) straight from the samples
+ * (hpc/affinity.c:181-193 + hpc/laplacian.c:31-35). out: (i1-i0) x p row-major. */
+int orc_laplacian_rows(const orc_params *prm, const uint8_t *img, int width, unsigned p, const unsigned *idx,
+                       const double *D, double alpha, unsigned i0, unsigned i1, double *out)
+{
+    if (i0 > i1 || i1 > p) return -1;
+#pragma omp parallel for schedule(static)
+    for (long i = i0; i < (long)i1; ++i) {
+        const double r0 = (double)(idx[i] / (unsigned)width), c0 = (double)(idx[i] % (unsigned)width);
+        const double v0 = (double)img[idx[i]];
+        for (unsigned j = 0; j < p; ++j) {
+            const double k = orc_kernel_entry(prm, r0, c0, v0, (double)(idx[j] / (unsigned)width),
+                                              (double)(idx[j] % (unsigned)width), (double)img[idx[j]]);
+            out[(size_t)(i - i0) * p + j] = (-1.0 * k + (((unsigned)i == j) ? D[i] : 0.0)) * alpha;
+        }
+    }
+    return 0;
+}
+
+/* Y (m vectors of length nrows) = Arows (nrows x p) * X (m vectors of length p). */
+int orc_matvec_rows(const double *Arows, unsigned nrows, unsigned p, const double *X, unsigned m, double *Y)
+{
+    double *Xr = (double *)malloc(sizeof(double) * (size_t)p * m);
+    if (!Xr) return -1;
+    for (unsigned j = 0; j < m; ++j)
+        for (unsigned i = 0; i < p; ++i) Xr[(size_t)i * m + j] = X[(size_t)j * p + i];
+#pragma omp parallel
+    {
+        double *acc = (double *)malloc(sizeof(double) * (m ? m : 1));
+#pragma omp for schedule(static)
+        for (long i = 0; i < (long)nrows; ++i) {
+            const double *Ai = Arows + (size_t)i * p;
+            for (unsigned j = 0; j < m; ++j) acc[j] = 0.0;
+            for (unsigned k = 0; k < p; ++k) {
+                const double a = Ai[k];
+                const double *xr = Xr + (size_t)k * m;
+                for (unsigned j = 0; j < m; ++j) acc[j] += a * xr[j];
+            }
+            for (unsigned j = 0; j < m; ++j) Y[(size_t)j * nrows + i] = acc[j];
+        }
+        free(acc);
+    }
+    free(Xr);
+    return 0;
+}
+
+/* Nystroem rows (hpc/nystroem.c:41-42) for the pixels of image rows [row0,row1), raster order,
+ * sample pixels included with the extension formula (they are overwritten by phi_A in the full
+ * path). out: m vectors of length (row1-row0)*width. */
+int orc_nystroem_rows(const orc_params *prm, const uint8_t *img, int width, int height, int row0, int row1,
+                      unsigned p, const unsigned *idx, double alpha, const double *phi_A, const double *eigvals,
+                      unsigned m, double *out)
+{
+    if (row0 < 0 || row1 > height || row0 > row1) return -1;
+    const size_t npix = (size_t)(row1 - row0) * width;
+    double *PL = (double *)malloc(sizeof(double) * (size_t)p * m);
+    double *sr = (double *)malloc(sizeof(double) * p * 3);
+    if (!PL || !sr) return -1;
+    double *sc = sr + p, *sv = sc + p;
+    for (unsigned i = 0; i < p; ++i) {
+        sr[i] = (double)(idx[i] / (unsigned)width);
+        sc[i] = (double)(idx[i] % (unsigned)width);
+        sv[i] = (double)img[idx[i]];
+        for (unsigned j = 0; j < m; ++j) PL[(size_t)i * m + j] = phi_A[(size_t)j * p + i] * (1. / eigvals[j]);
+    }
+#pragma omp parallel
+    {
+        double *acc = (double *)malloc(sizeof(double) * (m ? m : 1));
+#pragma omp for schedule(dynamic, 16)
+        for (long q = 0; q < (long)npix; ++q) {
+            const size_t px = (size_t)row0 * width + (size_t)q;
+            const double r = (double)(px / (unsigned)width), c = (double)(px % (unsigned)width), v = (double)img[px];
+            for (unsigned j = 0; j < m; ++j) acc[j] = 0.0;
+            for (unsigned i = 0; i < p; ++i) {
+                const double lb = -alpha * orc_kernel_entry(prm, sr[i], sc[i], sv[i], r, c, v);
+                const double *pl = PL + (size_t)i * m;
+                for (unsigned j = 0; j < m; ++j) acc[j] += lb * pl[j];
+            }
+            for (unsigned j = 0; j < m; ++j) out[(size_t)j * npix + q] = acc[j];
+        }
+        free(acc);
+    }
+    free(sr);
+    free(PL);
+    return 0;
+}

@@ -158,6 +158,14 @@ int orc_image_processing(const orc_params *prm, const uint8_t *img, int width, i
 int orc_entire_computation(const orc_params *prm, const uint8_t *img, int width, int height,
                            double *zf, uint8_t *out);
 
+/* Bounded-sample helpers for bench.py's cpu_baseline leg (same arithmetic on a slice). */
+int orc_laplacian_rows(const orc_params *prm, const uint8_t *img, int width, unsigned p, const unsigned *idx,
+                       const double *D, double alpha, unsigned i0, unsigned i1, double *out);
+int orc_matvec_rows(const double *Arows, unsigned nrows, unsigned p, const double *X, unsigned m, double *Y);
+int orc_nystroem_rows(const orc_params *prm, const uint8_t *img, int width, int height, int row0, int row1,
+                      unsigned p, const unsigned *idx, double alpha, const double *phi_A, const double *eigvals,
+                      unsigned m, double *out);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

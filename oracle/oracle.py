@@ -246,5 +246,43 @@ def entire_computation(img, prm=None):
     return zf.reshape(h, w), out.reshape(h, w)
 
 
+def laplacian_rows(img, idx, D, alpha, i0, i1, prm=None):
+    img = _img(img)
+    prm = prm or default_params()
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    out = np.empty((i1 - i0, idx.size))
+    rc = lib().orc_laplacian_rows(C.byref(prm), _p(img, C.c_uint8), img.shape[1], C.c_uint(idx.size),
+                                  _p(idx, C.c_uint), _p(D), C.c_double(alpha), C.c_uint(i0), C.c_uint(i1), _p(out))
+    assert rc == 0
+    return out
+
+
+def matvec_rows(Arows, X):
+    Arows = np.ascontiguousarray(Arows, dtype=np.float64)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    nrows, p = Arows.shape
+    m = X.shape[0]
+    Y = np.empty((m, nrows))
+    rc = lib().orc_matvec_rows(_p(Arows), C.c_uint(nrows), C.c_uint(p), _p(X), C.c_uint(m), _p(Y))
+    assert rc == 0
+    return Y
+
+
+def nystroem_rows(img, idx, alpha, phi_A, eigvals, row0, row1, prm=None):
+    img = _img(img)
+    prm = prm or default_params()
+    h, w = img.shape
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    phi_A = np.ascontiguousarray(phi_A, dtype=np.float64)
+    eigvals = np.ascontiguousarray(eigvals, dtype=np.float64)
+    m, p = phi_A.shape
+    out = np.empty((m, (row1 - row0) * w))
+    rc = lib().orc_nystroem_rows(C.byref(prm), _p(img, C.c_uint8), w, h, row0, row1, C.c_uint(p),
+                                 _p(idx, C.c_uint), C.c_double(alpha), _p(phi_A), _p(eigvals), C.c_uint(m), _p(out))
+    assert rc == 0
+    return out
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -4,7 +4,8 @@ golden vectors of the reference's Python PoC. Needs an MI355X: -m gpu.
 
 Tolerances (fp32 device arithmetic vs fp64 oracle; north_star asks for a stated
 fp64 -> fp32 PSNR tolerance):
-  kernel entries      rel 3e-6   (one v_exp_f32 + 5 roundings)
+  kernel entries      rel 3e-6 for entries >= 1e-6, rel 5e-5 below (the f32 rounding of the
+                      exponent t ~ 90 is amplified by exp: entries ~1e-27)
   degree D_A, alpha   rel 2e-6   (f32 within an image row, f64 across)
   L_A                 abs 3e-6 * max|L_A|
   eigenvalues         abs 2e-4   (same X0, same stopping rule)
@@ -20,6 +21,12 @@ pytestmark = pytest.mark.gpu
 import glf  # noqa: E402  (fails loudly when libglf.so is missing)
 import oracle as orc  # noqa: E402
 from conftest import psnr  # noqa: E402
+
+
+def assert_kernel_close(got, ref):
+    big = ref >= 1e-6
+    np.testing.assert_allclose(got[big], ref[big], rtol=3e-6)
+    np.testing.assert_allclose(got, ref, rtol=5e-5, atol=1e-37)
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +60,7 @@ def test_affinity_degree_laplacian(ctx, golden, png, name):
     d_img = ctx.to_device(img)
     K_A, K_B = ctx.ComputeAffinityMatrices(d_img, idx)
     KA_ref, _ = orc.affinity(img, idx, want_KB=False)
-    np.testing.assert_allclose(ctx.mat_to_numpy(K_A), KA_ref, rtol=3e-6, atol=1e-30)
+    assert_kernel_close(ctx.mat_to_numpy(K_A), KA_ref)
     D_ref = orc.degree(img, idx)
     np.testing.assert_allclose(ctx.degree_of(K_B), D_ref, rtol=2e-6)
     assert (K_B.kind, K_B.rows, K_B.cols, K_B.scale) == (glf.MAT_KERNEL_B, idx.size, h * w - idx.size, 1.0)
@@ -74,7 +81,7 @@ def test_other_kernels_against_golden(ctx, golden, kernel, ok):
     name = "photometric" if kernel == glf.KERNEL_PHOTOMETRIC else "spatial"
     d_img = ctx.to_device(g["img"])
     K_A, K_B = ctx.ComputeAffinityMatrices(d_img, g["idx"], kernel=kernel, h_loc=10.0, h_val=10.0)
-    np.testing.assert_allclose(ctx.mat_to_numpy(K_A), g["K_A_" + name], rtol=5e-6, atol=1e-30)
+    assert_kernel_close(ctx.mat_to_numpy(K_A), g["K_A_" + name])
     D_ref = g["K_A_" + name].sum(1) + g["K_B_" + name].sum(1)
     np.testing.assert_allclose(ctx.degree_of(K_B), D_ref, rtol=3e-6)
     ctx.destroy(K_A, K_B)
@@ -89,7 +96,7 @@ def test_stage_goldens_from_python_poc(ctx, golden, png):
         idx = glf.Sampling(w, h, p_req)
         np.testing.assert_array_equal(idx, g["idx"])
         K_A, K_B = ctx.ComputeAffinityMatrices(ctx.to_device(img), idx)
-        np.testing.assert_allclose(ctx.mat_to_numpy(K_A), g["K_A"], rtol=3e-6, atol=1e-30)
+        assert_kernel_close(ctx.mat_to_numpy(K_A), g["K_A"])
         np.testing.assert_allclose(ctx.degree_of(K_B), g["D_A"], rtol=2e-6)
         L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(K_A, K_B)
         assert alpha == pytest.approx(float(g["alpha"]), rel=2e-6)
@@ -109,7 +116,7 @@ def test_orthonormalise_and_normalise(ctx, n, m):
     Y = ctx.dense_from_numpy((X * 3.0).T)
     nn = ctx.NormaliseVecs(Y)
     np.testing.assert_allclose(nn, 3.0 * np.linalg.norm(X, axis=1), rtol=1e-6)
-    np.testing.assert_allclose(np.linalg.norm(ctx.mat_to_numpy(Y), axis=0), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(ctx.mat_to_numpy(Y).astype(np.float64), axis=0), 1.0, rtol=2e-6)
     ctx.destroy(Xd, Y)
 
 

@@ -276,3 +276,18 @@ def test_barbara_config2(golden, png):
     zf, out = orc.result_from_laplacian(img, phi, w[:64], gain=3.0)
     np.testing.assert_allclose(zf[::64], g["z_c_m64_rows"], rtol=1e-6, atol=2e-4)
     assert np.mean(out != g["z_c_m64_u8"]) < 1e-3
+
+
+def test_bounded_sample_helpers_agree_with_full_stages(golden):
+    """The slices bench.py times for cpu_baseline are the same arithmetic as the full stages."""
+    g = golden("syn32.npz")
+    img, idx, alpha = g["img"], g["idx"], float(g["alpha"])
+    np.testing.assert_allclose(orc.laplacian_rows(img, idx, g["D_A"], alpha, 2, 7), g["L_A"][2:7], rtol=1e-12, atol=1e-16)
+    X = orc.random_vectors(9, 3, 2)
+    np.testing.assert_allclose(orc.matvec_rows(g["L_A"][2:7], X), X.dot(g["L_A"][2:7].T), rtol=1e-12)
+    vecs, vals = _lapack_pairs(g["L_A"], 4)
+    full = orc.permutation(orc.nystroem(img, idx, alpha, vecs, vals), idx).reshape(4, 32, 32)
+    part = orc.nystroem_rows(img, idx, alpha, vecs, vals, 10, 14).reshape(4, 4, 32)
+    mask = np.ones((32, 32), dtype=bool)
+    mask.reshape(-1)[idx] = False
+    np.testing.assert_allclose(part[:, mask[10:14]], full[:, 10:14][:, mask[10:14]], rtol=1e-12)
