@@ -32,7 +32,9 @@ int build_sample_tables(glf_ctx *ctx, const uint8_t *d_img, int width, int heigh
         if ((int64_t)h_idx[i] >= N || (i && h_idx[i] <= h_idx[i - 1]))
             return set_error(ctx, GLF_ERR_INVALID, "sample_indices must be ascending and < width*height (i=%u)", i);
     }
-    GLF_TRY(out.samples.alloc(ctx, p));
+    const size_t p_pad = (size_t)round_up(p, NYS_PAD); // zero records past p (Nystroem LDS staging)
+    GLF_TRY(out.samples.alloc(ctx, p_pad));
+    GLF_HIP(ctx, hipMemsetAsync(out.samples.p, 0, sizeof(float4) * p_pad, ctx->stream));
     GLF_TRY(out.mask.alloc(ctx, (size_t)N));
     GLF_TRY(out.idx.alloc(ctx, p));
     GLF_HIP(ctx, hipMemcpyAsync(out.idx.p, h_idx, sizeof(uint32_t) * p, hipMemcpyHostToDevice, ctx->stream));

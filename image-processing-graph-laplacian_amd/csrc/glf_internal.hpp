@@ -27,6 +27,7 @@ struct glf_ctx {
 namespace glf {
 
 constexpr int WAVE = 64;
+constexpr int NYS_PAD = 64; // sample table and Psi are zero-padded to a multiple of this many rows
 
 inline int set_error(glf_ctx *ctx, int status, const char *fmt, ...)
 {

@@ -195,7 +195,8 @@ int glf_Nystroem(glf_ctx *ctx, const glf_mat *B, const glf_mat *phi_A, const glf
                          (long long)phi_A->rows, m, ld);
     const int64_t N = (int64_t)B->width * B->height;
     DevBuf<float> psi;
-    GLF_TRY(psi.alloc(ctx, (size_t)p * ld));
+    GLF_TRY(psi.alloc(ctx, (size_t)round_up(p, NYS_PAD) * ld));
+    GLF_HIP(ctx, hipMemsetAsync(psi.p, 0, sizeof(float) * (size_t)round_up(p, NYS_PAD) * ld, ctx->stream));
     hipLaunchKernelGGL(k_make_psi, dim3((unsigned)ceil_div((int64_t)p * ld, 256)), dim3(256), 0, ctx->stream, phi_A->data,
                        Pi_A_Inv->data, p, ld, m, B->scale, psi.p);
     GLF_LAUNCH_CHECK(ctx);
@@ -335,7 +336,8 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     // ---- Nystroem extension, written straight in raster order (Permutation folded in) ----------
     DevBuf<float> psi, pinv, phi, w;
     DevBuf<double> c;
-    GLF_TRY(psi.alloc(ctx, (size_t)p * ld));
+    GLF_TRY(psi.alloc(ctx, (size_t)round_up(p, NYS_PAD) * ld));
+    GLF_HIP(ctx, hipMemsetAsync(psi.p, 0, sizeof(float) * (size_t)round_up(p, NYS_PAD) * ld, st));
     GLF_TRY(pinv.alloc(ctx, ld));
     GLF_TRY(w.alloc(ctx, ld));
     GLF_TRY(c.alloc(ctx, ld));

@@ -98,7 +98,7 @@ typedef struct glf_mat {
     int32_t owns_data;   /* glf_mat_destroy frees data */
     /* generator descriptor (KERNEL_B): entry (i, col) = scale * K(sample i, pixel col) */
     const uint8_t *img;  /* device image */
-    const float *samples;/* device float4 per sample: {row, col, value, 0} */
+    const float *samples;/* device float4 per sample: {row, col, value, 0}, zero-padded to 64 records */
     const uint8_t *mask; /* device uint8[N]: 1 at sample pixels */
     const uint32_t *idx; /* device sample indices, ascending */
     int32_t width, height;
