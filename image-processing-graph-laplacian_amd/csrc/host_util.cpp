@@ -68,6 +68,14 @@ int glf_Sampling(int width, int height, unsigned *sample_size, unsigned **sample
     return GLF_OK;
 }
 
+int glf_shard_rows(int height, int rank, int size, int *row0, int *row1)
+{
+    if (height < 0 || size < 1 || rank < 0 || rank >= size || !row0 || !row1) return GLF_ERR_INVALID;
+    *row0 = (int)((long long)rank * height / size);
+    *row1 = (int)((long long)(rank + 1) * height / size);
+    return GLF_OK;
+}
+
 // X0 for the inverse subspace iteration: m vectors of length p, vector after
 // vector, U[0,1) (the reference fills with PETSc's rand48 seeded by the MPI
 // rank, hpc/inverse_power_it.c:27-34; that stream is third-party, so we fix our

@@ -10,8 +10,7 @@ namespace glf {
 static void shard_rows(const glf_ctx *ctx, int height, int *row0, int *row1)
 {
     const int G = ctx->has_comm ? ctx->comm.size : 1, g = ctx->has_comm ? ctx->comm.rank : 0;
-    *row0 = (int)((int64_t)g * height / G);
-    *row1 = (int)((int64_t)(g + 1) * height / G);
+    (void)glf_shard_rows(height, g, G, row0, row1);
 }
 
 static int allreduce_f64(glf_ctx *ctx, double *d, size_t n)

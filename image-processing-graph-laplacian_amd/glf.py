@@ -37,7 +37,7 @@ KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL = 0, 1, 2
 # every symbol include/glf.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
-    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
+    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_shard_rows", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
     "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_Sampling",
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
@@ -168,6 +168,41 @@ def write_png(path, img):
         raise GlfError(ERR_IO, path)
 
 
+def shard_rows(height, rank, size):
+    """Pixel rows [row0, row1) owned by `rank` (glf_shard_rows; used by glf_image_processing)."""
+    r0, r1 = C.c_int(), C.c_int()
+    rc = _lib.glf_shard_rows(C.c_int(height), C.c_int(rank), C.c_int(size), C.byref(r0), C.byref(r1))
+    if rc != OK:
+        raise GlfError(rc, "shard_rows(%d, %d, %d)" % (height, rank, size))
+    return r0.value, r1.value
+
+
+def device_tensor_from_ptr(ptr, count, dtype, device):
+    """Zero-copy torch view of `count` elements at device address `ptr`."""
+    iface = {"shape": (count,), "typestr": "<f8" if dtype == torch.float64 else "<f4",
+             "data": (ptr, False), "version": 2, "strides": None}
+
+    class _Holder:
+        __cuda_array_interface__ = iface
+    return torch.as_tensor(_Holder(), device=device)
+
+
+def make_comm(rank, size, allreduce):
+    """glf_comm whose callbacks call allreduce(ptr, count, is_f64) -> None (in place, sum over ranks).
+    Exceptions become a non-zero status (they cannot cross the C boundary). Keep the returned
+    struct alive for as long as the context uses it."""
+    def wrap(is_f64):
+        def cb(user, ptr, count):
+            try:
+                allreduce(ptr, count, is_f64)
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print("glf allreduce callback failed:", repr(exc))
+                return 1
+        return cb
+    return Comm(rank, size, ALLREDUCE_F32(wrap(False)), ALLREDUCE_F64(wrap(True)), None)
+
+
 # ---- device context --------------------------------------------------------------------
 
 class Context:
@@ -209,33 +244,22 @@ class Context:
         self._check(_lib.glf_ctx_device_info(self._ctx, name, C.c_size_t(256), C.byref(cus), C.byref(mem)))
         return dict(name=name.value.decode(), num_cus=cus.value, total_mem=mem.value)
 
-    # -- collectives: torch.distributed on tensors aliasing the device buffers ------------
+    # -- collectives ---------------------------------------------------------------------------
     def set_comm_torch(self, group=None):
-        """Plug torch.distributed all-reduces (RCCL on GPU) into glf_comm."""
+        """Plug torch.distributed all-reduces into glf_comm: RCCL on the device buffers in place
+        (backend "nccl"), or staged through host memory for a gloo group (CPU rehearsal of the
+        N > 1 path, several ranks sharing one GPU in tests)."""
         import torch.distributed as dist
         torch = self.torch
-        size = dist.get_world_size(group)
-        rank = dist.get_rank(group)
+        size, rank = dist.get_world_size(group), dist.get_rank(group)
         if size == 1:
             self._check(_lib.glf_ctx_set_comm(self._ctx, None))
             return
         dev = self.device
-
-        def as_tensor(ptr, count, dtype):
-            # zero-copy view of the library's device buffer
-            iface = {"shape": (count,), "typestr": "<f8" if dtype == torch.float64 else "<f4",
-                     "data": (ptr, False), "version": 2, "strides": None}
-
-            class _Holder:
-                __cuda_array_interface__ = iface
-            return torch.as_tensor(_Holder(), device=dev)
-
-        # RCCL reduces device buffers in place; a gloo group (CPU rehearsal of the N > 1 path,
-        # or several ranks sharing one GPU in tests) is staged through host memory.
         on_device = dist.get_backend(group) == "nccl"
 
-        def allreduce(ptr, count, dtype):
-            t = as_tensor(ptr, count, dtype)
+        def allreduce(ptr, count, is_f64):
+            t = device_tensor_from_ptr(ptr, count, torch.float64 if is_f64 else torch.float32, dev)
             if on_device:
                 dist.all_reduce(t, group=group)
             else:
@@ -243,25 +267,8 @@ class Context:
                 dist.all_reduce(h, group=group)
                 t.copy_(h)
 
-        def ar32(user, ptr, count):
-            try:
-                allreduce(ptr, count, torch.float32)
-                return 0
-            except Exception as exc:  # noqa: BLE001 - status code crosses the C boundary
-                print("glf allreduce_sum_f32 failed:", exc)
-                return 1
-
-        def ar64(user, ptr, count):
-            try:
-                allreduce(ptr, count, torch.float64)
-                return 0
-            except Exception as exc:  # noqa: BLE001
-                print("glf allreduce_sum_f64 failed:", exc)
-                return 1
-
-        comm = Comm(rank, size, ALLREDUCE_F32(ar32), ALLREDUCE_F64(ar64), None)
-        self._comm_keepalive = comm
-        self._check(_lib.glf_ctx_set_comm(self._ctx, C.byref(comm)))
+        self._comm_keepalive = make_comm(rank, size, allreduce)
+        self._check(_lib.glf_ctx_set_comm(self._ctx, C.byref(self._comm_keepalive)))
 
     # -- helpers ---------------------------------------------------------------------------
     def to_device(self, img):

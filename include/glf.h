@@ -75,6 +75,9 @@ typedef struct glf_comm {
     void *user;
 } glf_comm;
 int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm);
+/* The pixel-row shard of rank `rank` of `size`: rows [*row0, *row1) = [rank*height/size, (rank+1)*height/size).
+ * Host only (replaces PETSc's PETSC_DECIDE row ownership, hpc/utils.c:463-475). */
+int glf_shard_rows(int height, int rank, int size, int *row0, int *row1);
 
 /* Flat device buffers (replace MatCreate/VecCreate + MatDestroy/VecDestroy). */
 int glf_malloc(glf_ctx *ctx, void **dptr, size_t bytes);
