@@ -62,6 +62,11 @@ int glf_ctx_create(glf_ctx **out, int device, void *hip_stream)
         }
     ctx->comm.rank = 0;
     ctx->comm.size = 1;
+    if (const char *mode = std::getenv("GLF_CONTRACTION")) {
+        if (std::strcmp(mode, "f32") == 0) ctx->contraction = GLF_CONTRACT_F32_MFMA;
+        else if (std::strcmp(mode, "f16s") == 0) ctx->contraction = GLF_CONTRACT_F16_SPLIT;
+        else fprintf(stderr, "glf: ignoring GLF_CONTRACTION=%s (expected f32 or f16s)\n", mode);
+    }
     *out = ctx;
     return GLF_OK;
 }
@@ -109,6 +114,13 @@ int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm)
         return glf::set_error(ctx, GLF_ERR_INVALID, "glf_comm needs rank < size and both allreduce callbacks");
     ctx->comm = *comm;
     ctx->has_comm = true;
+    return GLF_OK;
+}
+
+int glf_ctx_set_contraction(glf_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != GLF_CONTRACT_F32_MFMA && mode != GLF_CONTRACT_F16_SPLIT)) return GLF_ERR_INVALID;
+    ctx->contraction = mode;
     return GLF_OK;
 }
 

@@ -22,6 +22,7 @@ struct glf_ctx {
     hipDeviceProp_t prop{};
     // reusable events for stage timing
     hipEvent_t ev[8] = {};
+    int contraction = GLF_CONTRACT_F16_SPLIT; // how glf_Nystroem / glf_image_processing contract K_B^T Psi
 };
 
 namespace glf {

@@ -14,6 +14,8 @@
 // VALU/transcendental-bound (kernel generation) below.
 #include "glf_internal.hpp"
 
+#include <cmath>
+
 namespace glf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -215,6 +217,276 @@ static int launch_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int64_
     return GLF_OK;
 }
 
+// =====================================================================================================
+// Split-f16 contraction: the same Phi = K^T Psi, but on the f16 matrix pipe so that the MFMAs overlap the
+// VALU kernel generation (the f32-input MFMA shares the f32 FMA pipe with the VALU and cannot: see
+// tools/mfma_probe.hip). Both operands are split into an f16 (hi, lo) pair with hi + lo carrying 22
+// significant bits:  K' = 2^15 K,  Psi' = T_j Psi (T_j a power of two per column, |Psi'| < 2^14);
+//   K' Psi' ~= Khi Phi_hi + Khi Plo + Klo Phi_hi     (the dropped lo*lo term is 2^-22 relative)
+// accumulated in f32 by v_mfma_f32_32x32x16_f16 and rescaled by 2^-15 / T_j (exact) in the epilogue.
+// A lane owns one pixel per 32-pixel block and generates K for 8 consecutive samples per 16-sample
+// MFMA step (A fragment: lane l holds A[row l&31][k = 8 (l>>5) + j], j = 0..7).
+// =====================================================================================================
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float NYS_F16_KSCALE_LOG2 = 15.0f; // K' = 2^15 K  (max 32768 < 65504)
+
+// Psi [p_pad][ld] f32  ->  per chunk of 64 samples: [step t (4)][jb (MB)][piece q (2)][lane (64)][8 halves]
+// (every (t, jb, q) fragment block is 1 KiB, lane-linear: one conflict-free ds_read_b128 per lane).
+__global__ __launch_bounds__(256) void k_psi_split_f16(const float *__restrict__ psi, unsigned p_pad, unsigned ld,
+                                                        const float *__restrict__ colscale, _Float16 *__restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)p_pad * ld) return;
+    const unsigned s = (unsigned)(e / ld), c = (unsigned)(e % ld);
+    const float v = psi[e] * colscale[c];
+    const _Float16 hi = (_Float16)v;                 // round to nearest
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const unsigned mb = ld / 32;
+    const unsigned chunk = s / 64, t = (s % 64) / 16, h = (s % 16) / 8, j = s % 8, jb = c / 32, r = c % 32;
+    const size_t frag = (((size_t)chunk * 4 + t) * mb + jb) * 2; // + q
+    const size_t lane = h * 32 + r;
+    out[((frag + 0) * 64 + lane) * 8 + j] = hi;
+    out[((frag + 1) * 64 + lane) * 8 + j] = lo;
+}
+
+// sample records {row, col, value, 0} x p_pad  ->  per chunk of 64: rows[64] cols[64] vals[64] pad[64]
+__global__ void k_samples_soa(const float4 *__restrict__ samples, unsigned p_pad, float *__restrict__ out)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p_pad) return;
+    const float4 v = samples[s];
+    float *o = out + (size_t)(s / 64) * 256 + (s % 64);
+    o[0] = v.x;
+    o[64] = v.y;
+    o[128] = v.z;
+    o[192] = 0.f;
+}
+
+__global__ void k_col_absmax(const float *__restrict__ psi, unsigned p, unsigned ld, float *__restrict__ out)
+{
+    __shared__ float sh[256];
+    const unsigned c = blockIdx.x;
+    float m = 0.f;
+    for (unsigned i = threadIdx.x; i < p; i += 256) m = fmaxf(m, fabsf(psi[(size_t)i * ld + c]));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sh[0];
+}
+
+template <int MB, int PB>
+__global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict__ img, int width, int64_t pix0, int64_t pix1,
+                                                        const float *__restrict__ soa, unsigned p, float s_loc, float s_val,
+                                                        const _Float16 *__restrict__ psi16, const float *__restrict__ invscale,
+                                                        float *__restrict__ phi, int raster,
+                                                        const uint8_t *__restrict__ mask, const uint32_t *__restrict__ idx,
+                                                        double *__restrict__ cpartial)
+{
+    constexpr int LD = MB * 32;
+    constexpr int PSI_F4 = 4 * MB * 2 * 64;      // float4 (16 B) words of one chunk's Psi fragments
+    constexpr int NV = PSI_F4 / 256;             // per thread
+    constexpr int BUF_F4 = 64 + PSI_F4;          // + 1 KiB sample SoA
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * BUF_F4];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int64_t wbase = pix0 + ((int64_t)blockIdx.x * 4 + wave) * (32 * PB);
+
+    float pr[PB], pc[PB], pv[PB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        int64_t px = wbase + 32 * b + (lane & 31);
+        if (px >= pix1) px = pix1 - 1;
+        pr[b] = (float)(px / width);
+        pc[b] = (float)(px % width);
+        pv[b] = (float)img[px];
+    }
+    f32x16 acc[PB][MB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
+
+    const int nchunks = (int)((p + 63) / 64);
+    const float4 *gsoa = reinterpret_cast<const float4 *>(soa);
+    const float4 *gpsi = reinterpret_cast<const float4 *>(psi16);
+    float4 stage_s, stage_p[NV];
+    auto g_load = [&](int chunk) {
+        if (threadIdx.x < 64) stage_s = gsoa[(size_t)chunk * 64 + threadIdx.x];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) stage_p[v] = gpsi[(size_t)chunk * PSI_F4 + v * 256 + threadIdx.x];
+    };
+    auto l_store = [&](int buf) {
+        float4 *dst = lds + buf * BUF_F4;
+        if (threadIdx.x < 64) dst[threadIdx.x] = stage_s;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[64 + v * 256 + threadIdx.x] = stage_p[v];
+    };
+    g_load(0);
+    l_store(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) g_load(ch + 1); // in flight during the MFMA/VALU sweep below
+        const float *ssoa = reinterpret_cast<const float *>(lds + buf * BUF_F4);
+        const f16x8 *sfrag = reinterpret_cast<const f16x8 *>(lds + buf * BUF_F4 + 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // this lane's 8 samples of the step: 16 t + 8 half + (0..7)
+            float sr[8], sc[8], sv[8];
+            {
+                const float4 *q = reinterpret_cast<const float4 *>(ssoa + 16 * t + 8 * half);
+                const float4 r0 = q[0], r1 = q[1], c0 = q[16], c1 = q[17], v0 = q[32], v1 = q[33];
+                sr[0] = r0.x; sr[1] = r0.y; sr[2] = r0.z; sr[3] = r0.w; sr[4] = r1.x; sr[5] = r1.y; sr[6] = r1.z; sr[7] = r1.w;
+                sc[0] = c0.x; sc[1] = c0.y; sc[2] = c0.z; sc[3] = c0.w; sc[4] = c1.x; sc[5] = c1.y; sc[6] = c1.z; sc[7] = c1.w;
+                sv[0] = v0.x; sv[1] = v0.y; sv[2] = v0.z; sv[3] = v0.w; sv[4] = v1.x; sv[5] = v1.y; sv[6] = v1.z; sv[7] = v1.w;
+            }
+            f16x8 ah[PB], al[PB];
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 y;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float dr = pr[b] - sr[e + u], dc = pc[b] - sc[e + u], dv = pv[b] - sv[e + u];
+                        const float q = fmaf(dc, dc, dr * dr);
+                        y[u] = __builtin_amdgcn_exp2f(NYS_F16_KSCALE_LOG2 - fmaf(dv * dv, s_val, q * s_loc));
+                    }
+                    const f16x2 h2 = __builtin_convertvector(y, f16x2);            // round to nearest
+                    const f32x2 res = y - __builtin_convertvector(h2, f32x2);      // exact in f32
+                    const f16x2 l2 = __builtin_convertvector(res, f16x2);
+                    ah[b][e] = h2[0];
+                    ah[b][e + 1] = h2[1];
+                    al[b][e] = l2[0];
+                    al[b][e + 1] = l2[1];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const f16x8 bh = sfrag[((t * MB + j) * 2 + 0) * 64 + lane];
+                const f16x8 bl = sfrag[((t * MB + j) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int b = 0; b < PB; ++b) {
+                    acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bh, acc[b][j], 0, 0, 0);
+                    acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bl, acc[b][j], 0, 0, 0);
+                    acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b], bh, acc[b][j], 0, 0, 0);
+                }
+            }
+        }
+        if (ch + 1 < nchunks) l_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (same as k_nystroem, plus the exact power-of-two rescale per column)
+    const int l31 = lane & 31;
+    float inv[MB], csum[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        inv[j] = invscale[32 * j + l31];
+        csum[j] = 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t px = wbase + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (px >= pix1) continue;
+            const bool is_sample = mask[px] != 0;
+            int64_t dst;
+            if (raster) dst = px;
+            else {
+                if (is_sample) continue;
+                dst = (int64_t)p + px - (int64_t)samples_before(idx, p, (uint32_t)px);
+            }
+            const float y = is_sample ? 0.f : (float)img[px];
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const float v = acc[b][j][r] * inv[j];
+                phi[(size_t)dst * LD + 32 * j + l31] = v;
+                csum[j] = fmaf(v, y, csum[j]);
+            }
+        }
+    }
+    if (cpartial) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds); // [4 waves][LD]
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            float v = csum[j] + __shfl_xor(csum[j], 32, 64);
+            if (half == 0) red[wave * LD + 32 * j + l31] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < LD)
+            cpartial[(size_t)blockIdx.x * LD + threadIdx.x] =
+                ((double)red[threadIdx.x] + (double)red[LD + threadIdx.x]) +
+                ((double)red[2 * LD + threadIdx.x] + (double)red[3 * LD + threadIdx.x]);
+    }
+}
+
+template <int MB, int PB>
+static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, int64_t pix0, int64_t pix1,
+                                const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
+                                KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms)
+{
+    constexpr unsigned LD = MB * 32;
+    const unsigned p_pad = (unsigned)round_up(p, NYS_PAD);
+    hipStream_t st = ctx->stream;
+    // per-column power-of-two scale T_j with |Psi| T_j < 2^14
+    DevBuf<float> colmax, colscale, invscale, soa;
+    DevBuf<_Float16> psi16;
+    GLF_TRY(colmax.alloc(ctx, LD));
+    GLF_TRY(colscale.alloc(ctx, LD));
+    GLF_TRY(invscale.alloc(ctx, LD));
+    GLF_TRY(soa.alloc(ctx, (size_t)p_pad * 4));
+    GLF_TRY(psi16.alloc(ctx, (size_t)p_pad * LD * 2));
+    hipLaunchKernelGGL(k_col_absmax, dim3(LD), dim3(256), 0, st, d_psi, p, LD, colmax.p);
+    GLF_LAUNCH_CHECK(ctx);
+    std::vector<float> hmax(LD), hscale(LD), hinv(LD);
+    GLF_HIP(ctx, hipMemcpyAsync(hmax.data(), colmax.p, sizeof(float) * LD, hipMemcpyDeviceToHost, st));
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    for (unsigned j = 0; j < LD; ++j) {
+        int e = 0;
+        if (hmax[j] > 0.f && std::isfinite(hmax[j])) {
+            (void)std::frexp(hmax[j], &e);   // hmax = f * 2^e, f in [0.5, 1)
+            e = 14 - e;                       // hmax * 2^e in [2^13, 2^14)
+        }
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+        hscale[j] = std::ldexp(1.0f, e);
+        hinv[j] = std::ldexp(1.0f, -e - (int)NYS_F16_KSCALE_LOG2);
+    }
+    GLF_HIP(ctx, hipMemcpyAsync(colscale.p, hscale.data(), sizeof(float) * LD, hipMemcpyHostToDevice, st));
+    GLF_HIP(ctx, hipMemcpyAsync(invscale.p, hinv.data(), sizeof(float) * LD, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_psi_split_f16, dim3((unsigned)ceil_div((int64_t)p_pad * LD, 256)), dim3(256), 0, st, d_psi, p_pad, LD,
+                       colscale.p, psi16.p);
+    hipLaunchKernelGGL(k_samples_soa, dim3((p_pad + 255) / 256), dim3(256), 0, st, d_samples, p_pad, soa.p);
+    GLF_LAUNCH_CHECK(ctx);
+
+    const int64_t npix = pix1 - pix0;
+    const int64_t nwg = ceil_div(npix, 4 * 32 * PB);
+    DevBuf<double> cpart;
+    if (d_c) GLF_TRY(cpart.alloc(ctx, (size_t)nwg * LD));
+    if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[6], st));
+    hipLaunchKernelGGL((k_nystroem_f16s<MB, PB>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
+                       coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr);
+    GLF_LAUNCH_CHECK(ctx);
+    if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    if (d_c) GLF_TRY(sum_rows(ctx, cpart.p, nwg, LD, d_c, true));
+    GLF_HIP(ctx, hipStreamSynchronize(st)); // hscale/hinv and the DevBufs go out of scope
+    if (kernel_ms) GLF_HIP(ctx, hipEventElapsedTime(kernel_ms, ctx->ev[6], ctx->ev[7]));
+    return GLF_OK;
+}
+
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float /*scale folded into psi*/, const float *d_psi, unsigned m, unsigned ld,
@@ -225,6 +497,15 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
         return set_error(ctx, GLF_ERR_INVALID, "nystroem_contract: bad range or ld=%u", ld);
     if (kernel_ms) *kernel_ms = 0.f;
     if (pix0 == pix1) return GLF_OK;
+    if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
+        switch (ld) {
+        case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        case 64: return launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        case 128: return launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        case 256: return launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        }
+        return GLF_ERR_UNSUPPORTED;
+    }
     switch (ld) {
     case 32:
         return launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);

@@ -33,11 +33,12 @@ ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_NODEVICE, ERR_COMM, ERR_NOCONV, ERR_IO, ERR
 MAT_DENSE, MAT_DIAG, MAT_KERNEL_B = 0, 1, 2
 ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
 KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL = 0, 1, 2
+CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
 
 # every symbol include/glf.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
-    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_shard_rows", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
+    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
     "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_Sampling",
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
@@ -234,6 +235,10 @@ class Context:
     def _check(self, rc, what=""):
         if rc != OK:
             raise GlfError(rc, (what + " " if what else "") + _lib.glf_ctx_last_error(self._ctx).decode())
+
+    def set_contraction(self, mode):
+        """CONTRACT_F32_MFMA or CONTRACT_F16_SPLIT (see include/glf.h)."""
+        self._check(_lib.glf_ctx_set_contraction(self._ctx, C.c_int(mode)))
 
     def synchronize(self):
         self._check(_lib.glf_ctx_synchronize(self._ctx))

@@ -8,7 +8,7 @@
  *        at hpc/read_img.c:47-50 selects): (6968 R + 23434 G + 2366 B) >> 15, and, when
  *        the file carries an sRGB or gAMA chunk, through libpng's 8-bit gamma tables
  *        (linearise, weight with +16384 rounding, re-encode) exactly as libpng 1.6 does.
- *        Both forms are pinned against real libpng output in tests/golden/*_gray_libpng.png.
+ *        Both forms are pinned against real libpng output in tests/golden/ (files ending in _gray_libpng.png).
  *        Anything else (gray+alpha, 16-bit, palette, interlaced) is rejected with -1
  *        instead of being silently misread (survey quirk Q13).
  * write: 8-bit gray, non-interlaced (hpc/write_img.c:38-45).

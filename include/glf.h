@@ -75,6 +75,16 @@ typedef struct glf_comm {
     void *user;
 } glf_comm;
 int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm);
+
+/* How the Nystroem contraction L_B^T (phi_A Pi^-1) (hpc/nystroem.c:42) is evaluated:
+ *  F32_MFMA   v_mfma_f32_32x32x2_f32, operands exactly f32 (shares the f32 FMA pipe with the
+ *             kernel generation: about 75 % of the f32 matrix peak);
+ *  F16_SPLIT  both operands split into f16 (hi, lo) pairs carrying 22 significant bits, three
+ *             v_mfma_f32_32x32x16_f16 products, f32 accumulation; runs on the f16 matrix pipe so the
+ *             MFMAs overlap the VALU generation (2.5x faster). Default; override per context here or
+ *             with the environment variable GLF_CONTRACTION=f32|f16s at context creation. */
+enum { GLF_CONTRACT_F32_MFMA = 1, GLF_CONTRACT_F16_SPLIT = 2 };
+int glf_ctx_set_contraction(glf_ctx *ctx, int mode);
 /* The pixel-row shard of rank `rank` of `size`: rows [*row0, *row1) = [rank*height/size, (rank+1)*height/size).
  * Host only (replaces PETSc's PETSC_DECIDE row ownership, hpc/utils.c:463-475). */
 int glf_shard_rows(int height, int rank, int size, int *row0, int *row1);

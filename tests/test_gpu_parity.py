@@ -29,11 +29,14 @@ def assert_kernel_close(got, ref):
     np.testing.assert_allclose(got, ref, rtol=5e-5, atol=1e-37)
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["f16s", "f32"])
+def ctx(request):
+    """Every test runs with both evaluations of the Nystroem contraction (include/glf.h):
+    split-f16 operands on the f16 matrix pipe (default) and exact f32-input MFMA."""
     import torch
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     c = glf.Context(0)
+    c.set_contraction(glf.CONTRACT_F16_SPLIT if request.param == "f16s" else glf.CONTRACT_F32_MFMA)
     yield c
     c.close()
 

@@ -101,6 +101,55 @@ __global__ __launch_bounds__(256) void k_valu_only(float *out, int iters, float 
     out[blockIdx.x * 256 + threadIdx.x] = accv[0] + accv[1];
 }
 
+// V3: generation in VALU, contraction on the f16 matrix pipe with split operands
+// (K = hi + lo in f16, Psi = hi + lo in f16; products hi*hi + hi*lo + lo*hi, f32 accumulate).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
+template <int PB, int MB, int NPROD>
+__global__ __launch_bounds__(256) void k_gen_f16(float *out, int iters, float s_loc, float s_val)
+{
+    f32x16 acc[PB][MB];
+    for (int b = 0; b < PB; ++b) for (int j = 0; j < MB; ++j) for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
+    float pr[PB], pc[PB], pv[PB];
+    for (int b = 0; b < PB; ++b) { pr[b] = threadIdx.x + b; pc[b] = threadIdx.x * 3 + b; pv[b] = (threadIdx.x * 7 + b) & 255; }
+    float sx = 1.f, sy = 2.f, sz = 3.f;
+    f16x8 bh[MB], bl[MB];
+    for (int j = 0; j < MB; ++j) for (int e = 0; e < 8; ++e) { bh[j][e] = (_Float16)(0.5f + j + e); bl[j][e] = (_Float16)(0.001f * e); }
+    for (int it = 0; it < iters; ++it) {
+        f16x8 ah[PB], al[PB];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                float y[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float dr = pr[b] - (sx + e + u), dc = pc[b] - (sy + e + u), dv = pv[b] - (sz + e + u);
+                    const float q = fmaf(dc, dc, dr * dr);
+                    y[u] = __builtin_amdgcn_exp2f(15.f - fmaf(dv * dv, s_val, q * s_loc));
+                }
+                const f16x2 h = __builtin_amdgcn_cvt_pkrtz(y[0], y[1]);
+                const float r0 = y[0] - (float)h[0], r1 = y[1] - (float)h[1];
+                const f16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+                ah[b][e] = (_Float16)h[0]; ah[b][e + 1] = (_Float16)h[1];
+                al[b][e] = (_Float16)l[0]; al[b][e + 1] = (_Float16)l[1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bh[j], acc[b][j], 0, 0, 0);
+                if (NPROD >= 2) acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bl[j], acc[b][j], 0, 0, 0);
+                if (NPROD >= 3) acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b], bh[j], acc[b][j], 0, 0, 0);
+            }
+        sx += 16.f; sy += 0.5f; sz += 0.25f;
+    }
+    float s = 0.f;
+    for (int b = 0; b < PB; ++b) for (int j = 0; j < MB; ++j) for (int r = 0; r < 16; ++r) s += acc[b][j][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // V2: as V1 but sample records and psi come from LDS like the real kernel
 template <int PB, int MB>
 __global__ __launch_bounds__(256) void k_gen_lds(float *out, int iters, float s_loc, float s_val)
@@ -179,6 +228,22 @@ int main()
         // cycles per generated A VGPR per SIMD: 8 waves per SIMD, 2 values per iteration
         const double cyc = 2.4e6 / (8.0 * it * 2.0);
         printf("valu-only scalar: %.3f ms = %.1f cyc per A value;  packed: %.3f ms = %.1f cyc per A value\n", ms0, ms0 * cyc, ms1, ms1 * cyc);
+    }
+    {
+        // entries (K evaluations) per second: f32 path = PB values per iteration per lane, f16 path = 8*PB
+        auto eps = [&](double ms, double vals_per_lane) { return vals_per_lane * 256.0 * WG / (ms * 1e-3); };
+        double ms = time_ms([&] { hipLaunchKernelGGL((k_gen<2, 2>), dim3(WG), dim3(256), 0, 0, out, it, 1e-3f, 2e-3f); });
+        printf("entries/s  f32 MFMA PB2 MB2        : %.3e\n", eps(ms, 2.0 * it));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_gen_f16<2, 2, 3>), dim3(WG), dim3(256), 0, 0, out, it / 8, 1e-3f, 2e-3f); });
+        printf("entries/s  f16x2 split 3 products   : %.3e  (%.3f ms)\n", eps(ms, 16.0 * (it / 8)), ms);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_gen_f16<2, 2, 1>), dim3(WG), dim3(256), 0, 0, out, it / 8, 1e-3f, 2e-3f); });
+        printf("entries/s  f16 single product       : %.3e  (%.3f ms)\n", eps(ms, 16.0 * (it / 8)), ms);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_gen_f16<1, 2, 3>), dim3(WG), dim3(256), 0, 0, out, it / 4, 1e-3f, 2e-3f); });
+        printf("entries/s  f16x2 split PB1          : %.3e  (%.3f ms)\n", eps(ms, 8.0 * (it / 4)), ms);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_gen_f16<2, 4, 3>), dim3(WG), dim3(256), 0, 0, out, it / 8, 1e-3f, 2e-3f); });
+        printf("entries/s  f16x2 split MB4 (m=128)  : %.3e  (%.3f ms)\n", eps(ms, 16.0 * (it / 8)), ms);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_valu_only<0>), dim3(WG), dim3(256), 0, 0, out, it, 1e-3f, 2e-3f); });
+        printf("entries/s  VALU generation only     : %.3e\n", eps(ms, 2.0 * it));
     }
     report("gen+lds PB2 MB2", time_ms([&] { hipLaunchKernelGGL((k_gen_lds<2, 2>), dim3(WG), dim3(256), 0, 0, out, it / 32, 1e-3f, 2e-3f); }), (it / 32) * 32 * 4.0);
     report("gen+lds PB1 MB2", time_ms([&] { hipLaunchKernelGGL((k_gen_lds<1, 2>), dim3(WG), dim3(256), 0, 0, out, it / 16, 1e-3f, 2e-3f); }), (it / 16) * 32 * 2.0);
