@@ -78,6 +78,7 @@ int glf_ctx_destroy(glf_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GLF_OK;

@@ -95,14 +95,246 @@ __global__ __launch_bounds__(256) void k_block_matvec(const float *__restrict__ 
         }
 }
 
+
+// =====================================================================================
+// Y = A X on the f16 matrix pipe with split operands (same scheme as k_nystroem_f16s):
+//   A' = 2^10 A = Ahi + Alo (split on the fly from the f32 stream),  X' = T_j X = Xhi + Xlo
+//   (fragment-ordered, prepared once per mat-vec), three v_mfma_f32_32x32x16_f16 products,
+//   f32 accumulation, exact power-of-two rescale in the epilogue.
+// The f32-input MFMA above needs 6 ms of the shared f32 FMA pipe per 29 GB sweep; this one needs
+// about 1 ms of the f16 pipe, which leaves the kernel bound by the HBM stream of L_A.
+// Lane (r = l & 31, h = l >> 5) loads the 32 consecutive floats A[row r][k0 + 32 h ...) of every
+// 64-wide K tile (one 128-B line); MFMA step t of the tile contracts k = k0 + 32 h + 8 t + j.
+// =====================================================================================
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int MV_ASCALE_LOG2 = 10;
+
+__global__ void k_mv_col_absmax(const float *__restrict__ X, unsigned p, unsigned ld, float *__restrict__ out)
+{
+    __shared__ float sh[256];
+    const unsigned c = blockIdx.x;
+    float m = 0.f;
+    for (unsigned i = threadIdx.x; i < p; i += 256) m = fmaxf(m, fabsf(X[(size_t)i * ld + c]));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // power-of-two T with max * T in [2^13, 2^14); 1 for an all-zero / non-finite column
+        const float mx = sh[0];
+        int ex = 0;
+        if (mx > 0.f && mx < 3.0e38f) ex = 13 - ilogbf(mx);
+        ex = max(-100, min(100, ex));
+        out[c] = ldexpf(1.0f, ex);                           // scale
+        out[ld + c] = ldexpf(1.0f, -ex - MV_ASCALE_LOG2);    // inverse of (scale * 2^10)
+    }
+}
+
+// X f32 [p_pad][ld] -> fragments [ktile][t (4)][jb][q (2)][lane (64)][8 halves]
+__global__ __launch_bounds__(256) void k_mv_x_split(const float *__restrict__ X, unsigned p_pad, unsigned ld,
+                                                     const float *__restrict__ scales, _Float16 *__restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)p_pad * ld) return;
+    const unsigned s = (unsigned)(e / ld), c = (unsigned)(e % ld);
+    const float v = X[e] * scales[c];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const unsigned mb = ld / 32;
+    const unsigned kt = s / 64, h = (s % 64) / 32, t = (s % 32) / 8, j = s % 8, jb = c / 32, r = c % 32;
+    const size_t frag = (((size_t)kt * 4 + t) * mb + jb) * 2;
+    const size_t lane = h * 32 + r;
+    out[((frag + 0) * 64 + lane) * 8 + j] = hi;
+    out[((frag + 1) * 64 + lane) * 8 + j] = lo;
+}
+
+// A is SYMMETRIC (L_A; the reference requires it too: "A is symmetric (and square)",
+// hpc/inverse_power_it.c:82-85), so the A-fragment element A[row r][k] is read as A[k][row r]:
+// for a fixed k the 32 lanes of a wave half read 32 consecutive floats of row k -- every load
+// instruction is two fully used 128-B lines, and the 4 waves of a workgroup cover 512 contiguous
+// bytes of that row. (Reading A[row r][k..k+7] directly makes each lane walk its own row: 64
+// different lines per instruction, 16 B used of each, the rest re-fetched through a thrashing
+// L1 -- measured 2.6 TB/s.)
+template <int MB>
+__global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restrict__ A, int64_t lda, unsigned p,
+                                                            unsigned p_pad, unsigned row_begin, unsigned row_end,
+                                                            const _Float16 *__restrict__ xfrag,
+                                                            const float *__restrict__ scales, float *__restrict__ Y,
+                                                            float *__restrict__ Ypart)
+{
+    constexpr int LD = MB * 32;
+    constexpr int FR_F4 = 4 * MB * 2 * 64; // float4 words of one K tile's X fragments
+    constexpr int NV = FR_F4 / 256;
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * FR_F4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned rbase = row_begin + blockIdx.x * 128 + wave * 32;
+    const unsigned row = rbase + l31;
+    const unsigned rowc = row < row_end ? row : row_end - 1; // clamp loads, skip the store
+    const float *acol = A + rowc + (size_t)(32 * half) * lda; // element (k = 32 half + i, rowc) at acol[i * lda]
+    const float4 *gfr = reinterpret_cast<const float4 *>(xfrag);
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    // K split: blockIdx.y sweeps tiles [kt_begin, kt_end); with gridDim.y > 1 the partial sums go to
+    // slab blockIdx.y of Ypart and k_mv_sum_splits adds them in fixed order.
+    const int ntiles = p_pad / 64;
+    const int kt_begin = (int)((int64_t)ntiles * blockIdx.y / gridDim.y);
+    const int kt_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / gridDim.y);
+    float a_cur[32], a_nxt[32];
+    float4 xs[NV];
+    auto load_a = [&](int kt, float (&dst)[32]) {
+        const unsigned k0 = (unsigned)kt * 64 + 32 * half;
+        if (kt + 1 < ntiles) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dst[i] = acol[(size_t)kt * 64 * lda + (size_t)i * lda];
+        } else { // last tile: rows k >= p do not exist (their X rows are zero): clamp the address
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const unsigned k = min(k0 + i, p - 1);
+                dst[i] = A[(size_t)k * lda + rowc];
+            }
+        }
+    };
+    if (kt_begin < kt_end) {
+        load_a(kt_begin, a_cur);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) lds[v * 256 + threadIdx.x] = gfr[(size_t)kt_begin * FR_F4 + v * 256 + threadIdx.x];
+    }
+    __syncthreads();
+    const float ascale = (float)(1 << MV_ASCALE_LOG2);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
+            load_a(kt + 1, a_nxt);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xs[v] = gfr[(size_t)(kt + 1) * FR_F4 + v * 256 + threadIdx.x];
+        }
+        const f16x8 *fr = reinterpret_cast<const f16x8 *>(lds + buf * FR_F4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f16x8 ah, al;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                f32x2 y = {a_cur[8 * t + e] * ascale, a_cur[8 * t + e + 1] * ascale};
+                const f16x2 h2 = __builtin_convertvector(y, f16x2);
+                const f32x2 res = y - __builtin_convertvector(h2, f32x2);
+                const f16x2 l2 = __builtin_convertvector(res, f16x2);
+                ah[e] = h2[0];
+                ah[e + 1] = h2[1];
+                al[e] = l2[0];
+                al[e + 1] = l2[1];
+            }
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                const f16x8 bh = fr[((t * MB + b) * 2 + 0) * 64 + lane];
+                const f16x8 bl = fr[((t * MB + b) * 2 + 1) * 64 + lane];
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < kt_end) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) lds[(buf ^ 1) * FR_F4 + v * 256 + threadIdx.x] = xs[v];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
+        }
+        __syncthreads();
+    }
+    float *dst = gridDim.y > 1 ? Ypart + (size_t)blockIdx.y * p_pad * LD : Y;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+        const float inv = gridDim.y > 1 ? 1.0f : scales[LD + 32 * b + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (orow < row_end) dst[(size_t)orow * LD + 32 * b + l31] = acc[b][r] * inv;
+        }
+    }
+}
+
+// Y[i][c] = inv[c] * sum_s Ypart[s][i][c]  (fixed order)
+__global__ __launch_bounds__(256) void k_mv_sum_splits(const float *__restrict__ Ypart, int nsplit, unsigned p_pad,
+                                                        unsigned row_begin, unsigned row_end, unsigned ld,
+                                                        const float *__restrict__ scales, float *__restrict__ Y)
+{
+    const size_t e = (size_t)row_begin * ld + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)row_end * ld) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += Ypart[(size_t)k * p_pad * ld + e];
+    Y[e] = s * scales[ld + (unsigned)(e % ld)];
+}
+
+static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld)
+{
+    const unsigned p_pad = (unsigned)round_up(p, VEC_PAD);
+    hipStream_t st = ctx->stream;
+    // scratch lives in the context (reused by every mat-vec of a solve; no allocation in the loop)
+    // K split so that the grid fills the 2-workgroups-per-CU residency evenly (the kernel keeps
+    // 64 VGPRs of A tile in flight: 2 waves per SIMD)
+    const int nrb = (int)ceil_div(p, 128);
+    const int slots = 2 * ctx->prop.multiProcessorCount;
+    int ksplit = 1;
+    {
+        double best = 0.0;
+        const int ntiles = (int)(p_pad / 64);
+        for (int ks = 1; ks <= 8 && ks <= ntiles; ++ks) {
+            const double wgs = (double)nrb * ks;
+            const double eff = wgs / (std::ceil(wgs / slots) * slots);
+            if (eff > best + 0.02) { best = eff; ksplit = ks; }
+        }
+    }
+    const size_t part_bytes = ksplit > 1 ? (size_t)ksplit * p_pad * ld * sizeof(float) : 0;
+    const size_t frag_bytes = (size_t)p_pad * ld * 2 * sizeof(_Float16);
+    const size_t need = 256 + 2 * ld * sizeof(float) + frag_bytes + part_bytes;
+    if (ctx->mv_scratch_bytes < need) {
+        if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
+        ctx->mv_scratch = nullptr;
+        ctx->mv_scratch_bytes = 0;
+        GLF_HIP(ctx, hipMalloc(&ctx->mv_scratch, need));
+        ctx->mv_scratch_bytes = need;
+    }
+    float *scales = reinterpret_cast<float *>(ctx->mv_scratch);
+    char *base = reinterpret_cast<char *>(ctx->mv_scratch) + round_up(2 * ld * sizeof(float), 256);
+    _Float16 *xfrag = reinterpret_cast<_Float16 *>(base);
+    float *ypart = ksplit > 1 ? reinterpret_cast<float *>(base + frag_bytes) : nullptr;
+    hipLaunchKernelGGL(k_mv_col_absmax, dim3(ld), dim3(256), 0, st, X, p, ld, scales);
+    hipLaunchKernelGGL(k_mv_x_split, dim3((unsigned)ceil_div((int64_t)p_pad * ld, 256)), dim3(256), 0, st, X, p_pad, ld, scales,
+                       xfrag);
+    dim3 grid((unsigned)nrb, (unsigned)ksplit), block(256);
+    switch (ld / 32) {
+    case 1: hipLaunchKernelGGL(k_block_matvec_f16s<1>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
+    case 2: hipLaunchKernelGGL(k_block_matvec_f16s<2>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
+    case 4: hipLaunchKernelGGL(k_block_matvec_f16s<4>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
+    case 8: hipLaunchKernelGGL(k_block_matvec_f16s<8>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
+    default: return set_error(ctx, GLF_ERR_UNSUPPORTED, "ld %u", ld);
+    }
+    if (ksplit > 1)
+        hipLaunchKernelGGL(k_mv_sum_splits, dim3((unsigned)ceil_div((int64_t)p * ld, 256)), dim3(256), 0, st, ypart, ksplit, p_pad,
+                           0u, p, ld, scales, Y);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
 int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld)
 {
-    const unsigned p32 = (unsigned)round_up(p, 32);
+    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     if (lda < (int64_t)p32 || (lda & 3) || !valid_ld(ld))
-        return set_error(ctx, GLF_ERR_INVALID, "block_matvec: lda=%lld ld=%u (need lda >= round_up(p,32), lda%%4==0, ld%%32==0, ld<=256)",
+        return set_error(ctx, GLF_ERR_INVALID, "block_matvec: lda=%lld ld=%u (need lda >= round_up(p,64), lda%%4==0, ld%%32==0, ld<=256)",
                          (long long)lda, ld);
     if (reinterpret_cast<uintptr_t>(A) & 15)
         return set_error(ctx, GLF_ERR_INVALID, "block_matvec: A must be 16-byte aligned");
+    if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) return block_matvec_f16s(ctx, A, lda, p, X, Y, ld);
     dim3 grid((unsigned)ceil_div(p, 128)), block(256);
     switch (ld / 32) {
     case 1: hipLaunchKernelGGL(k_block_matvec<1>, grid, block, 0, ctx->stream, A, lda, p, p32, X, Y); break;
@@ -322,7 +554,7 @@ struct CgWork {
     }
     int init(glf_ctx *ctx, unsigned p, unsigned ld)
     {
-        const size_t n = (size_t)round_up(p, 32) * ld;
+        const size_t n = (size_t)round_up(p, VEC_PAD) * ld;
         GLF_TRY(R.alloc(ctx, n));
         GLF_TRY(P.alloc(ctx, n));
         GLF_TRY(AP.alloc(ctx, n));
@@ -347,7 +579,7 @@ struct CgWork {
 static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, unsigned p, float *XB, unsigned m,
                           unsigned ld, double rtol, int max_it, int *iters)
 {
-    const unsigned p32 = (unsigned)round_up(p, 32);
+    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const int nblk = w.nblk;
     const unsigned nelem_blocks = (unsigned)ceil_div((int64_t)p * ld, 256);
     hipStream_t st = ctx->stream;
@@ -642,7 +874,7 @@ struct ResWork {
     int nchunks = 0;
     int init(glf_ctx *ctx, unsigned p, unsigned ld)
     {
-        const unsigned p32 = (unsigned)round_up(p, 32);
+        const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
         nchunks = (int)ceil_div(p32, GRAM_ROWS);
         GLF_TRY(AX.alloc(ctx, (size_t)p32 * ld));
         GLF_HIP(ctx, hipMemsetAsync(AX.p, 0, sizeof(float) * (size_t)p32 * ld, ctx->stream));
@@ -657,7 +889,7 @@ struct ResWork {
 static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
                         unsigned ld, double *h_out)
 {
-    const unsigned p32 = (unsigned)round_up(p, 32);
+    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const int nblk = (int)ceil_div(p, RED_ROWS);
     hipStream_t st = ctx->stream;
     GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld));
@@ -695,7 +927,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     if (m == 0 || m > p || !valid_ld(ld) || m > ld)
         return set_error(ctx, GLF_ERR_INVALID, "inverse_power_iteration: m=%u ld=%u p=%u (m <= 256 supported)", m, ld, p);
     if (opti_gs < 1) opti_gs = 1; // hpc/image_processing.c:128-140
-    const unsigned p32 = (unsigned)round_up(p, 32);
+    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const size_t n = (size_t)p32 * ld;
     hipStream_t st = ctx->stream;
 

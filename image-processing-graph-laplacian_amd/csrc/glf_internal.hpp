@@ -22,12 +22,15 @@ struct glf_ctx {
     hipDeviceProp_t prop{};
     // reusable events for stage timing
     hipEvent_t ev[8] = {};
+    void *mv_scratch = nullptr; // split-f16 X fragments of the block mat-vec
+    size_t mv_scratch_bytes = 0;
     int contraction = GLF_CONTRACT_F16_SPLIT; // how glf_Nystroem / glf_image_processing contract K_B^T Psi
 };
 
 namespace glf {
 
 constexpr int WAVE = 64;
+constexpr int VEC_PAD = 64; // rows of vector blocks / lda of L_A are padded to a multiple of this (zeros)
 constexpr int NYS_PAD = 64; // sample table and Psi are zero-padded to a multiple of this many rows
 
 inline int set_error(glf_ctx *ctx, int status, const char *fmt, ...)

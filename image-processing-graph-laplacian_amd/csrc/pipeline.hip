@@ -75,7 +75,7 @@ int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const 
     GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     if (K_A) {
-        const int64_t lda = round_up(p, 32);
+        const int64_t lda = round_up(p, VEC_PAD);
         GLF_TRY(glf_mat_create_dense(ctx, K_A, p, p, lda)); // zero-filled incl. padding
         GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, K_A->data, lda, false, 0.0, nullptr));
     }
@@ -111,7 +111,7 @@ int glf_ComputeLaplacianMatrix(glf_ctx *ctx, glf_mat *L_A, glf_mat *L_B, const g
     double sum = 0.0;
     GLF_TRY(sum_host(ctx, K_B->degree, p, &sum));
     const double alpha = 1.0 / (sum / (double)p);
-    const int64_t lda = round_up(p, 32);
+    const int64_t lda = round_up(p, VEC_PAD);
     GLF_TRY(glf_mat_create_dense(ctx, L_A, p, p, lda));
     const KernelCoef coef = make_coef(K_B->kernel, K_B->h_loc, K_B->h_val);
     if (K_A)
@@ -138,7 +138,7 @@ int glf_InversePowerIteration(glf_ctx *ctx, const glf_mat *A, unsigned m, glf_ma
     if (m == 0 || m >= p) return set_error(ctx, GLF_ERR_INVALID, "need 0 < m < p (m=%u p=%u)", m, p);
     if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "m = %u > 256 eigenpairs not supported", m);
     const unsigned ld = ld_for(m);
-    const unsigned p32 = (unsigned)round_up(p, 32);
+    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     glf_mat vecs;
     GLF_TRY(glf_mat_create_dense(ctx, &vecs, p32, m, ld));
     vecs.rows = p;
@@ -288,7 +288,7 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     if (m == 0 || m >= p) m = p - 1;
     if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "num_eigvals = %u > 256 not supported (p = %u)", m, p);
     const unsigned ld = ld_for(m);
-    const unsigned p32 = (unsigned)round_up(p, 32);
+    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const KernelCoef coef = make_coef(opt.kernel, opt.h_loc, opt.h_val);
     int row0, row1;
     shard_rows(ctx, height, &row0, &row1);

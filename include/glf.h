@@ -13,7 +13,7 @@
  * Layout conventions (all device matrices are float32, ROW-major):
  *   image        uint8  [height][width]            (x = idx / width is the row,
  *                                                   y = idx % width the column, hpc/utils.c:11-19)
- *   K_A, L_A     float  [p][p]
+ *   K_A, L_A     float  [p][lda]  lda = p rounded up to 64, zero padding (the eigen stages need it)
  *   X, Phi_A     float  [p][ld]   ld = m rounded up to 32, columns >= m are zero
  *   Phi          float  [N][ld]   row order GLF_ROWS_SAMPLE_FIRST or GLF_ROWS_RASTER
  *   K_B, L_B     never stored: a GLF_MAT_KERNEL_B descriptor (image + sample table + scale)

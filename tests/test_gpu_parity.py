@@ -134,7 +134,7 @@ def test_inverse_power_iteration_matches_oracle(ctx, golden, png, name, m, eps):
     p = idx.size
     X0 = glf.random_vectors(p, m, 1)
     vecs_ref, vals_ref, st_ref = orc.inverse_power_iteration(LA, m, X0, epsilon=eps, inner_rtol=1e-5)
-    A = ctx.dense_from_numpy(LA, ld=(p + 31) // 32 * 32)
+    A = ctx.dense_from_numpy(LA, ld=(p + 63) // 64 * 64)
     vecs, vals, st = ctx.InversePowerIteration(A, m, epsilon=eps, inner_rtol=1e-5, X0=X0)
     assert abs(st["outer_its"] - st_ref["outer_its"]) <= 1
     assert st["residual"] <= eps
@@ -148,7 +148,7 @@ def test_inverse_power_iteration_matches_oracle(ctx, golden, png, name, m, eps):
 
 def test_inverse_power_iteration_edge_cases(ctx, golden):
     LA = golden("syn32.npz")["L_A"]
-    A = ctx.dense_from_numpy(LA, ld=32)
+    A = ctx.dense_from_numpy(LA, ld=64)
     with pytest.raises(glf.GlfError):
         ctx.InversePowerIteration(A, 0)
     with pytest.raises(glf.GlfError):
