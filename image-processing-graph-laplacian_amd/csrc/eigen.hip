@@ -626,81 +626,119 @@ int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, 
 // Classical Gram-Schmidt (hpc/gram_schmidt.c:29-64), column k at a time
 // =====================================================================================
 
-// partial[blk][0][j] = sum_i X[i][k] X[i][j], partial[blk][1][j] = sum_i X[i][j]^2   (j < k; j == k gives ||x_k||^2)
+// Two launches per column. The projection proj_u(v) = <v,u>/<u,u> u (hpc/gram_schmidt.c:11-21) does
+// not depend on the length of u, so the columns stay un-normalised during the sweep (q[j] = <u_j,u_j>
+// is kept instead) and one final pass applies VecNormalize (:59) to all of them; norms[k] = sqrt(q[k])
+// is the same pre-normalisation norm the reference returns.
+
+// partial[blk][j] = sum_{i in blk} X[i][k] X[i][j]   (j < k)
 __global__ __launch_bounds__(256) void k_gs_dots(const float *__restrict__ X, unsigned n, unsigned ld, unsigned k,
                                                   double *__restrict__ partial)
 {
-    __shared__ double sh[2 * 256];
+    __shared__ double sh[256];
     const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
-    double v[2] = {0.0, 0.0};
+    double v[1] = {0.0};
     const unsigned base = blockIdx.x * RED_ROWS;
-    if (col <= (int)k) {
+    if (col < (int)k) {
         for (unsigned r = rl; r < RED_ROWS; r += nrl) {
             const unsigned i = base + r;
             if (i >= n) break;
-            const float xj = X[(size_t)i * ld + col], xk = X[(size_t)i * ld + k];
-            v[0] += (double)xk * (double)xj;
-            v[1] += (double)xj * (double)xj;
+            v[0] += (double)X[(size_t)i * ld + k] * (double)X[(size_t)i * ld + col];
         }
     }
-    block_col_reduce<2>(v, ld, partial, sh);
+    block_col_reduce<1>(v, ld, partial, sh);
 }
 
-// coef[j] = <x_k, u_j> / <u_j, u_j>  (Projection, hpc/gram_schmidt.c:11-21)
-__global__ void k_gs_coef(const double *__restrict__ partial, int nblk, unsigned ld, unsigned k, float *__restrict__ coef)
+// x_k <- x_k - sum_{j<k} coef[j] u_j with coef[j] = (sum_blk partial[blk][j]) / q[j]  (VecAXPBY :53);
+// normpart[k][blk] = sum_{i in blk} x_k[i]^2. Every workgroup rebuilds coef (and q[k-1], which
+// workgroup 0 also publishes) from the partial buffers in a fixed order.
+__global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned k, int nblk,
+                                                   const double *__restrict__ partial, double *__restrict__ q,
+                                                   double *__restrict__ normpart)
 {
-    const int c = threadIdx.x;
-    if (c >= (int)ld) return;
-    double d = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        d += partial[((size_t)b * 2 + 0) * ld + c];
-        q += partial[((size_t)b * 2 + 1) * ld + c];
+    __shared__ double sh[256];
+    __shared__ float coef[256];
+    __shared__ double qprev;
+    const int t = threadIdx.x;
+    // q[k-1] = sum_blk normpart[k-1][blk]
+    if (k > 0) {
+        double s = 0.0;
+        for (int b = t; b < nblk; b += 256) s += normpart[(size_t)(k - 1) * nblk + b];
+        sh[t] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) sh[t] += sh[t + o];
+            __syncthreads();
+        }
+        if (t == 0) {
+            qprev = sh[0];
+            if (blockIdx.x == 0) q[k - 1] = sh[0];
+        }
+        __syncthreads();
     }
-    coef[c] = (c < (int)k && q != 0.0) ? (float)(d / q) : 0.f;
-}
-
-// x_k <- x_k - sum_{j<k} coef[j] u_j (VecAXPBY :53); partial ||x_k||^2. One wave per row group.
-__global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned k,
-                                                   const float *__restrict__ coef, double *__restrict__ partial)
-{
-    __shared__ double shn[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // coef[j], j < k: column j's partials summed by 256/ld row lanes, then combined
+    {
+        const int col = t % ld, rl = t / ld, nrl = 256 / ld;
+        double s = 0.0;
+        if (col < (int)k)
+            for (int b = rl; b < nblk; b += nrl) s += partial[(size_t)b * ld + col];
+        __syncthreads();
+        sh[t] = s;
+        __syncthreads();
+        if (t < (int)ld) {
+            double d = 0.0;
+            for (int r = 0; r < nrl; ++r) d += sh[r * ld + col];
+            const double qq = (col + 1 == (int)k) ? qprev : (col < (int)k ? q[col] : 0.0);
+            coef[col] = (col < (int)k && qq != 0.0) ? (float)(d / qq) : 0.f;
+        }
+        __syncthreads();
+    }
+    // rows: ld/4 lanes per row, float4 each
+    const int lpr = ld / 4, q4 = t % lpr, rl = t / lpr, rpp = 256 / lpr;
+    const float4 c4 = make_float4(coef[4 * q4], coef[4 * q4 + 1], coef[4 * q4 + 2], coef[4 * q4 + 3]);
+    const bool owner = (int)(k / 4) == q4;
     double nrm = 0.0;
     const unsigned base = blockIdx.x * RED_ROWS;
-    for (unsigned r = wave; r < RED_ROWS; r += 4) {
+    for (unsigned r = rl; r < RED_ROWS; r += rpp) {
         const unsigned i = base + r;
-        if (i >= n) break;
-        float s = 0.f;
-        for (unsigned j = lane; j < k; j += 64) s = fmaf(coef[j], X[(size_t)i * ld + j], s);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) {
-            const float xn = X[(size_t)i * ld + k] - s;
-            X[(size_t)i * ld + k] = xn;
-            nrm += (double)xn * (double)xn;
+        const bool ok = i < n; // whole row group leaves together only if all rows are past the end
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) x = *reinterpret_cast<const float4 *>(&X[(size_t)i * ld + 4 * q4]);
+        float s = x.x * c4.x + x.y * c4.y + x.z * c4.z + x.w * c4.w;
+        for (int o = lpr / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (ok && owner) {
+            const float xk = (k % 4 == 0 ? x.x : k % 4 == 1 ? x.y : k % 4 == 2 ? x.z : x.w) - s;
+            X[(size_t)i * ld + k] = xk;
+            nrm += (double)xk * (double)xk;
         }
     }
-    if (lane == 0) shn[wave] = nrm;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = shn[0] + shn[1] + shn[2] + shn[3];
-}
-
-// norm[k] = sqrt(sum partial); scale column k by 1/norm (VecNormalize :59)
-__global__ void k_gs_norm(const double *__restrict__ partial, int nblk, unsigned k, double *__restrict__ norms)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += partial[b];
-        norms[k] = sqrt(s);
+    sh[t] = nrm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
+        __syncthreads();
     }
+    if (t == 0) normpart[(size_t)k * nblk + blockIdx.x] = sh[0];
 }
 
-__global__ void k_scale_col(float *__restrict__ X, unsigned n, unsigned ld, unsigned k, const double *__restrict__ norms)
+// q[m-1] from its partials, norms[j] = sqrt(q[j])
+__global__ void k_gs_norms(const double *__restrict__ normpart, int nblk, unsigned m, double *__restrict__ q,
+                           double *__restrict__ norms)
 {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double nr = norms[k];
-    if (nr != 0.0) X[(size_t)i * ld + k] = (float)((double)X[(size_t)i * ld + k] / nr);
+    __shared__ double sh[256];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int b = t; b < nblk; b += 256) s += normpart[(size_t)(m - 1) * nblk + b];
+    sh[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
+        __syncthreads();
+    }
+    if (t == 0) q[m - 1] = sh[0];
+    __syncthreads();
+    if (t < (int)m) norms[t] = sqrt(q[t]);
 }
 
 // column norms only (NormaliseVecs, hpc/gram_schmidt.c:66-77)
@@ -738,45 +776,41 @@ __global__ void k_scale_all(float *__restrict__ X, unsigned n, unsigned ld, unsi
     if (nr != 0.0) X[e] = (float)((double)X[e] / nr);
 }
 
-static int orthonormalise_dev(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *d_partial,
-                              float *d_coef, double *d_norms)
-{
-    const int nblk = (int)ceil_div(n, RED_ROWS);
-    hipStream_t st = ctx->stream;
-    for (unsigned k = 0; k < m; ++k) {
-        if (k > 0) {
-            hipLaunchKernelGGL(k_gs_dots, dim3(nblk), dim3(256), 0, st, X, n, ld, k, d_partial);
-            hipLaunchKernelGGL(k_gs_coef, dim3(1), dim3(256), 0, st, d_partial, nblk, ld, k, d_coef);
-        }
-        hipLaunchKernelGGL(k_gs_apply, dim3(nblk), dim3(256), 0, st, X, n, ld, k, d_coef, d_partial);
-        hipLaunchKernelGGL(k_gs_norm, dim3(1), dim3(64), 0, st, d_partial, nblk, k, d_norms);
-        hipLaunchKernelGGL(k_scale_col, dim3((n + 255) / 256), dim3(256), 0, st, X, n, ld, k, d_norms);
-    }
-    GLF_LAUNCH_CHECK(ctx);
-    return GLF_OK;
-}
-
 struct GsWork {
-    DevBuf<double> partial, norms;
-    DevBuf<float> coef;
+    DevBuf<double> partial, norms, q, normpart;
+    int nblk = 0;
     int init(glf_ctx *ctx, unsigned n, unsigned ld)
     {
-        const int nblk = (int)ceil_div(n, RED_ROWS);
+        nblk = (int)ceil_div(n, RED_ROWS);
         GLF_TRY(partial.alloc(ctx, (size_t)nblk * 2 * ld));
         GLF_TRY(norms.alloc(ctx, ld));
-        GLF_TRY(coef.alloc(ctx, ld));
-        GLF_HIP(ctx, hipMemsetAsync(coef.p, 0, sizeof(float) * ld, ctx->stream));
+        GLF_TRY(q.alloc(ctx, ld));
+        GLF_TRY(normpart.alloc(ctx, (size_t)nblk * ld));
         GLF_HIP(ctx, hipMemsetAsync(norms.p, 0, sizeof(double) * ld, ctx->stream));
+        GLF_HIP(ctx, hipMemsetAsync(q.p, 0, sizeof(double) * ld, ctx->stream));
         return GLF_OK;
     }
 };
+
+static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld)
+{
+    hipStream_t st = ctx->stream;
+    for (unsigned k = 0; k < m; ++k) {
+        if (k > 0) hipLaunchKernelGGL(k_gs_dots, dim3(w.nblk), dim3(256), 0, st, X, n, ld, k, w.partial.p);
+        hipLaunchKernelGGL(k_gs_apply, dim3(w.nblk), dim3(256), 0, st, X, n, ld, k, w.nblk, w.partial.p, w.q.p, w.normpart.p);
+    }
+    hipLaunchKernelGGL(k_gs_norms, dim3(1), dim3(256), 0, st, w.normpart.p, w.nblk, m, w.q.p, w.norms.p);
+    hipLaunchKernelGGL(k_scale_all, dim3((unsigned)ceil_div((int64_t)n * ld, 256)), dim3(256), 0, st, X, n, ld, m, w.norms.p);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
 
 int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms)
 {
     if (!valid_ld(ld) || m > ld) return set_error(ctx, GLF_ERR_INVALID, "orthonormalise: ld=%u m=%u", ld, m);
     GsWork w;
     GLF_TRY(w.init(ctx, n, ld));
-    GLF_TRY(orthonormalise_dev(ctx, X, n, m, ld, w.partial.p, w.coef.p, w.norms.p));
+    GLF_TRY(orthonormalise_dev(ctx, w, X, n, m, ld));
     if (h_norms) GLF_HIP(ctx, hipMemcpyAsync(h_norms, w.norms.p, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;
@@ -957,7 +991,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
     GLF_LAUNCH_CHECK(ctx);
 
-    GLF_TRY(orthonormalise_dev(ctx, X.p, p, m, ld, gs.partial.p, gs.coef.p, gs.norms.p)); // :95
+    GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :95
     // The reference leaves X_k_before_orth unset when the loop never runs (:97-101); define it.
     GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
     double r_norm = 0.0;
@@ -975,11 +1009,11 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         inner_total += inner;
         GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st)); // CopyVecs :171
         if (it % opti_gs == 0)
-            GLF_TRY(orthonormalise_dev(ctx, X.p, p, m, ld, gs.partial.p, gs.coef.p, gs.norms.p)); // :174-177
+            GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :174-177
         GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :180
     }
     if (opti_gs != 1 && (it % opti_gs) != 0)
-        GLF_TRY(orthonormalise_dev(ctx, X.p, p, m, ld, gs.partial.p, gs.coef.p, gs.norms.p)); // :183-186
+        GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :183-186
 
     if (h_eigvals) { // eigenvalues = 1 / norms, :204
         std::vector<double> nr(m);
