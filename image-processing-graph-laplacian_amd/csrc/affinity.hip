@@ -175,11 +175,13 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
 __global__ __launch_bounds__(256) void k_sample_matrix(const float4 *__restrict__ samples, unsigned p, float s_loc,
                                                         float s_val, float *__restrict__ out, int64_t ld,
                                                         int laplacian, double alpha,
-                                                        const double *__restrict__ degree)
+                                                        const double *__restrict__ degree, unsigned col0,
+                                                        unsigned ncols)
 {
-    const unsigned j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const unsigned jl = blockIdx.x * 64 + (threadIdx.x & 63); // local column
     const unsigned i0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
-    if (j >= p) return;
+    if (jl >= ncols) return;
+    const unsigned j = col0 + jl;
     const float4 sj = samples[j];
     const float fscale = laplacian ? (float)(-alpha) : 1.0f;
 #pragma unroll 4
@@ -190,16 +192,21 @@ __global__ __launch_bounds__(256) void k_sample_matrix(const float4 *__restrict_
         float k = kernel_eval(si.x - sj.x, si.y - sj.y, si.z - sj.z, s_loc, s_val);
         float v = fscale * k;
         if (laplacian && i == j) v = (float)(alpha * (degree[i] - (double)k));
-        out[(size_t)i * ld + j] = v;
+        out[(size_t)i * ld + jl] = v;
     }
 }
 
 int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef, float *d_out,
-                        int64_t ld, bool laplacian, double alpha, const double *d_degree)
+                        int64_t ld, bool laplacian, double alpha, const double *d_degree, unsigned col0, unsigned ncols)
 {
-    dim3 grid((p + 63) / 64, (p + 63) / 64);
+    if (ncols == 0) {
+        col0 = 0;
+        ncols = p;
+    }
+    if (col0 + ncols > p) return set_error(ctx, GLF_ERR_INVALID, "build_sample_matrix: column range");
+    dim3 grid((ncols + 63) / 64, (p + 63) / 64);
     hipLaunchKernelGGL(k_sample_matrix, grid, dim3(256), 0, ctx->stream, d_samples, p, coef.s_loc, coef.s_val, d_out,
-                       ld, laplacian ? 1 : 0, alpha, d_degree);
+                       ld, laplacian ? 1 : 0, alpha, d_degree, col0, ncols);
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
 }

@@ -15,6 +15,7 @@
 #include "glf_internal.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace glf {
 
@@ -275,14 +276,19 @@ __global__ __launch_bounds__(256) void k_mv_sum_splits(const float *__restrict__
     Y[e] = s * scales[ld + (unsigned)(e % ld)];
 }
 
-static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld)
+static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld,
+                             const MatShard *shard)
 {
     const unsigned p_pad = (unsigned)round_up(p, VEC_PAD);
+    const bool sharded = shard && shard->rows_per_rank;
+    const unsigned row0 = sharded ? shard->row0 : 0u, row1 = sharded ? shard->row1 : p;
+    // element (k, row) of the symmetric operator sits at A[k * lda + (row - row0)]
+    const float *A_eff = A - row0;
     hipStream_t st = ctx->stream;
     // scratch lives in the context (reused by every mat-vec of a solve; no allocation in the loop)
     // K split so that the grid fills the 2-workgroups-per-CU residency evenly (the kernel keeps
     // 64 VGPRs of A tile in flight: 2 waves per SIMD)
-    const int nrb = (int)ceil_div(p, 128);
+    const int nrb = (int)ceil_div(row1 > row0 ? row1 - row0 : 1u, 128);
     const int slots = 2 * ctx->prop.multiProcessorCount;
     int ksplit = 1;
     {
@@ -311,30 +317,41 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
     hipLaunchKernelGGL(k_mv_col_absmax, dim3(ld), dim3(256), 0, st, X, p, ld, scales);
     hipLaunchKernelGGL(k_mv_x_split, dim3((unsigned)ceil_div((int64_t)p_pad * ld, 256)), dim3(256), 0, st, X, p_pad, ld, scales,
                        xfrag);
-    dim3 grid((unsigned)nrb, (unsigned)ksplit), block(256);
-    switch (ld / 32) {
-    case 1: hipLaunchKernelGGL(k_block_matvec_f16s<1>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
-    case 2: hipLaunchKernelGGL(k_block_matvec_f16s<2>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
-    case 4: hipLaunchKernelGGL(k_block_matvec_f16s<4>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
-    case 8: hipLaunchKernelGGL(k_block_matvec_f16s<8>, grid, block, 0, st, A, lda, p, p_pad, 0u, p, xfrag, scales, Y, ypart); break;
-    default: return set_error(ctx, GLF_ERR_UNSUPPORTED, "ld %u", ld);
+    if (row1 > row0) {
+        dim3 grid((unsigned)nrb, (unsigned)ksplit), block(256);
+        switch (ld / 32) {
+        case 1: hipLaunchKernelGGL(k_block_matvec_f16s<1>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
+        case 2: hipLaunchKernelGGL(k_block_matvec_f16s<2>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
+        case 4: hipLaunchKernelGGL(k_block_matvec_f16s<4>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
+        case 8: hipLaunchKernelGGL(k_block_matvec_f16s<8>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
+        default: return set_error(ctx, GLF_ERR_UNSUPPORTED, "ld %u", ld);
+        }
+        if (ksplit > 1)
+            hipLaunchKernelGGL(k_mv_sum_splits, dim3((unsigned)ceil_div((int64_t)(row1 - row0) * ld, 256)), dim3(256), 0, st, ypart,
+                               ksplit, p_pad, row0, row1, ld, scales, Y);
     }
-    if (ksplit > 1)
-        hipLaunchKernelGGL(k_mv_sum_splits, dim3((unsigned)ceil_div((int64_t)p * ld, 256)), dim3(256), 0, st, ypart, ksplit, p_pad,
-                           0u, p, ld, scales, Y);
     GLF_LAUNCH_CHECK(ctx);
+    if (sharded) { // every rank needs the whole Y: in-place all-gather of the row blocks
+        if (!ctx->has_comm || !ctx->comm.allgather_f32) return set_error(ctx, GLF_ERR_COMM, "sharded mat-vec without allgather_f32");
+        if (ctx->comm.allgather_f32(ctx->comm.user, Y, (size_t)shard->rows_per_rank * ld) != 0)
+            return set_error(ctx, GLF_ERR_COMM, "allgather_f32 callback failed");
+    }
     return GLF_OK;
 }
 
-int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld)
+int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld,
+                 const MatShard *shard)
 {
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
-    if (lda < (int64_t)p32 || (lda & 3) || !valid_ld(ld))
+    const bool sharded = shard && shard->rows_per_rank;
+    if (sharded && ctx->contraction != GLF_CONTRACT_F16_SPLIT)
+        return set_error(ctx, GLF_ERR_UNSUPPORTED, "row-sharded mat-vec needs the split-f16 contraction");
+    if ((!sharded && lda < (int64_t)p32) || (lda & 3) || !valid_ld(ld))
         return set_error(ctx, GLF_ERR_INVALID, "block_matvec: lda=%lld ld=%u (need lda >= round_up(p,64), lda%%4==0, ld%%32==0, ld<=256)",
                          (long long)lda, ld);
     if (reinterpret_cast<uintptr_t>(A) & 15)
         return set_error(ctx, GLF_ERR_INVALID, "block_matvec: A must be 16-byte aligned");
-    if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) return block_matvec_f16s(ctx, A, lda, p, X, Y, ld);
+    if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) return block_matvec_f16s(ctx, A, lda, p, X, Y, ld, shard);
     dim3 grid((unsigned)ceil_div(p, 128)), block(256);
     switch (ld / 32) {
     case 1: hipLaunchKernelGGL(k_block_matvec<1>, grid, block, 0, ctx->stream, A, lda, p, p32, X, Y); break;
@@ -552,9 +569,11 @@ struct CgWork {
     {
         if (h_nactive) (void)hipHostFree(h_nactive);
     }
-    int init(glf_ctx *ctx, unsigned p, unsigned ld)
+    const MatShard *shard = nullptr;
+    int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
     {
-        const size_t n = (size_t)round_up(p, VEC_PAD) * ld;
+        shard = sh;
+        const size_t n = (size_t)vec_rows(p, sh, ctx->comm.size) * ld;
         GLF_TRY(R.alloc(ctx, n));
         GLF_TRY(P.alloc(ctx, n));
         GLF_TRY(AP.alloc(ctx, n));
@@ -591,7 +610,7 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
     GLF_HIP(ctx, hipStreamSynchronize(st));
     while (*w.h_nactive > 0 && it < max_it) {
         ++it;
-        GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld));
+        GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld, w.shard));
         hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p, w.AP.p, p, ld, w.partial.p);
         hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.s);
         hipLaunchKernelGGL(k_cg_update, dim3(nblk), dim3(256), 0, st, w.Xs.p, w.R.p, w.P.p, w.AP.p, w.dinv.p, p, ld, w.s,
@@ -906,12 +925,15 @@ struct ResWork {
     DevBuf<float> AX, Gpart, G;
     DevBuf<double> partial, sums;
     int nchunks = 0;
-    int init(glf_ctx *ctx, unsigned p, unsigned ld)
+    const MatShard *shard = nullptr;
+    int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
     {
+        shard = sh;
         const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
+        const size_t vr = vec_rows(p, sh, ctx->comm.size);
         nchunks = (int)ceil_div(p32, GRAM_ROWS);
-        GLF_TRY(AX.alloc(ctx, (size_t)p32 * ld));
-        GLF_HIP(ctx, hipMemsetAsync(AX.p, 0, sizeof(float) * (size_t)p32 * ld, ctx->stream));
+        GLF_TRY(AX.alloc(ctx, vr * ld));
+        GLF_HIP(ctx, hipMemsetAsync(AX.p, 0, sizeof(float) * vr * ld, ctx->stream));
         GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
         GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
         GLF_TRY(partial.alloc(ctx, (size_t)ceil_div(p, RED_ROWS) * ld));
@@ -926,7 +948,7 @@ static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, u
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const int nblk = (int)ceil_div(p, RED_ROWS);
     hipStream_t st = ctx->stream;
-    GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld));
+    GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld, w.shard));
     const int mb = ld / 32;
     hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X, w.AX.p, p32, ld, w.Gpart.p);
     hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 255) / 256), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
@@ -956,13 +978,15 @@ int residual_norm(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const f
 
 int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
                             const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
-                            float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats)
+                            float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats, const MatShard *shard,
+                            const float *d_dinv)
 {
     if (m == 0 || m > p || !valid_ld(ld) || m > ld)
         return set_error(ctx, GLF_ERR_INVALID, "inverse_power_iteration: m=%u ld=%u p=%u (m <= 256 supported)", m, ld, p);
     if (opti_gs < 1) opti_gs = 1; // hpc/image_processing.c:128-140
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
-    const size_t n = (size_t)p32 * ld;
+    const size_t n = (size_t)vec_rows(p, shard, ctx->comm.size) * ld; // >= p32 * ld
+    const size_t n_out = (size_t)p32 * ld;                           // what the caller's d_eigvecs holds
     hipStream_t st = ctx->stream;
 
     DevBuf<float> X, Xb;
@@ -985,10 +1009,15 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     GsWork gs;
     GLF_TRY(gs.init(ctx, p, ld));
     CgWork cg;
-    GLF_TRY(cg.init(ctx, p, ld));
+    GLF_TRY(cg.init(ctx, p, ld, shard));
     ResWork rs;
-    GLF_TRY(rs.init(ctx, p, ld));
-    hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
+    GLF_TRY(rs.init(ctx, p, ld, shard));
+    if (d_dinv) // Jacobi preconditioner supplied by the caller (a sharded A does not hold the whole diagonal)
+        GLF_HIP(ctx, hipMemcpyAsync(cg.dinv.p, d_dinv, sizeof(float) * p, hipMemcpyDeviceToDevice, st));
+    else if (shard && shard->rows_per_rank)
+        return set_error(ctx, GLF_ERR_INVALID, "sharded inverse iteration needs the diagonal (d_dinv)");
+    else
+        hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
     GLF_LAUNCH_CHECK(ctx);
 
     GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :95
@@ -996,6 +1025,8 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
     double r_norm = 0.0;
     GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :159
+    const bool verbose = std::getenv("GLF_VERBOSE") != nullptr; // the reference logs every outer iteration (:164-181)
+    if (verbose) fprintf(stderr, "[glf rank %d] initial residual %.9g\n", ctx->comm.rank, r_norm);
     int it = 0, inner_total = 0, rc = GLF_OK;
     while (r_norm > epsilon) { // :161
         if (it >= max_outer) {
@@ -1011,6 +1042,8 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         if (it % opti_gs == 0)
             GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :174-177
         GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :180
+        if (verbose)
+            fprintf(stderr, "[glf rank %d] outer iteration %d: %d block-CG steps, residual %.9g\n", ctx->comm.rank, it, inner, r_norm);
     }
     if (opti_gs != 1 && (it % opti_gs) != 0)
         GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :183-186
@@ -1023,7 +1056,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     }
     if (d_eigvecs) { // NormaliseVecs(X_k_before_orth), :230
         GLF_TRY(normalise_dev(ctx, Xb.p, p, m, ld, gs.partial.p, gs.norms.p));
-        GLF_HIP(ctx, hipMemcpyAsync(d_eigvecs, Xb.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        GLF_HIP(ctx, hipMemcpyAsync(d_eigvecs, Xb.p, sizeof(float) * n_out, hipMemcpyDeviceToDevice, st));
     }
     GLF_HIP(ctx, hipStreamSynchronize(st));
     if (stats) {

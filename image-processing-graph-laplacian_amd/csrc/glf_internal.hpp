@@ -136,15 +136,32 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
                 const float4 *d_samples, unsigned p, KernelCoef coef, double *d_degree);
 
 // K_A (scale = 1, diag untouched) or L_A (scale = -alpha, diagonal alpha * D_i).
+// columns [col0, col0 + ncols) only (ncols = 0: all p columns); out is [p][ld] with local column index
 int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef,
-                        float *d_out, int64_t ld, bool laplacian, double alpha, const double *d_degree);
+                        float *d_out, int64_t ld, bool laplacian, double alpha, const double *d_degree,
+                        unsigned col0 = 0, unsigned ncols = 0);
 int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, float *d_LA, int64_t ld,
                       double alpha, const double *d_degree);
 
 // Eigensolver pieces (eigen.hip)
-struct EigWork; // opaque workspace
+// Row sharding of the symmetric p x p operator over the ranks of ctx->comm: this rank computes output
+// rows [row0,row1) of A X and holds only the matching COLUMN block A[:, row0:row1) (= the transposed row
+// block), stored [p][lda] with element (k, row) at A[k * lda + (row - row0)]. rows_per_rank is the
+// all-gather block (a multiple of 64 >= ceil(p / size)); 0 = not sharded (A is the full matrix).
+struct MatShard {
+    unsigned row0 = 0, row1 = 0, rows_per_rank = 0;
+};
+inline unsigned shard_rows_per_rank(unsigned p, int size) { return (unsigned)round_up(ceil_div(p, size), VEC_PAD); }
+// rows to allocate for a p x ld vector block (zero padded) so that the all-gather blocks fit
+inline unsigned vec_rows(unsigned p, const MatShard *sh, int size)
+{
+    const unsigned base = (unsigned)round_up(p, VEC_PAD);
+    if (!sh || !sh->rows_per_rank) return base;
+    const unsigned g = sh->rows_per_rank * (unsigned)size;
+    return g > base ? g : base;
+}
 int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y,
-                 unsigned mld);
+                 unsigned mld, const MatShard *shard = nullptr);
 int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms);
 int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms);
 int residual_norm(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
@@ -153,7 +170,8 @@ int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, 
               double rtol, int max_it, int *iters);
 int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
                             const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
-                            float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats);
+                            float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats,
+                            const MatShard *shard = nullptr, const float *d_dinv = nullptr);
 
 // Nystroem contraction (nystroem.hip): Phi[pix][j] = sum_i scale*K(sample i, pix) * Psi[i][j]
 // for pixels [pix0, pix1). raster != 0: row = pix; else sample-first (rows of sample pixels skipped).

@@ -31,6 +31,13 @@ __global__ void k_make_psi(const float *__restrict__ phiA, const float *__restri
     psi[e] = (j < m) ? scale * (phiA[e] * pinv[j]) : 0.f;
 }
 
+// Jacobi preconditioner of L_A without the matrix: 1 / (alpha (D_i - K_ii)), K_ii = 1 (hpc/laplacian.c:31-35)
+__global__ void k_dinv_from_degree(const double *__restrict__ degree, unsigned p, double alpha, float *__restrict__ dinv)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p) dinv[i] = 1.0f / (float)(alpha * (degree[i] - 1.0));
+}
+
 __global__ void k_diag_inverse(const float *__restrict__ x, unsigned n, float *__restrict__ y)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,10 +319,27 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     GLF_TRY(sum_host(ctx, deg.p, p, &dsum));
     const double alpha = 1.0 / (dsum / (double)p);
     S.alpha = alpha;
-    DevBuf<float> LA;
-    GLF_TRY(LA.alloc(ctx, (size_t)p * p32));
-    GLF_HIP(ctx, hipMemsetAsync(LA.p, 0, sizeof(float) * (size_t)p * p32, st));
-    GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, p32, true, alpha, deg.p));
+    // With a communicator that can all-gather, L_A is sharded: rank g holds the column block
+    // L_A[:, r0:r1) (= its row block transposed; L_A is symmetric) and computes rows [r0,r1) of every
+    // mat-vec. Otherwise (single GPU, f32 contraction, or no allgather callback) L_A is whole.
+    MatShard shard;
+    const bool shard_eig = ctx->has_comm && ctx->comm.allgather_f32 && ctx->contraction == GLF_CONTRACT_F16_SPLIT;
+    if (shard_eig) {
+        shard.rows_per_rank = shard_rows_per_rank(p, ctx->comm.size);
+        const uint64_t b = (uint64_t)shard.rows_per_rank * (unsigned)ctx->comm.rank;
+        shard.row0 = (unsigned)(b < p ? b : p);
+        shard.row1 = (unsigned)(b + shard.rows_per_rank < p ? b + shard.rows_per_rank : p);
+    }
+    const unsigned la_cols = shard_eig ? shard.row1 - shard.row0 : p;
+    const int64_t lda = shard_eig ? round_up(la_cols ? la_cols : 1, VEC_PAD) : (int64_t)p32;
+    DevBuf<float> LA, dinv;
+    GLF_TRY(LA.alloc(ctx, (size_t)p * lda));
+    GLF_HIP(ctx, hipMemsetAsync(LA.p, 0, sizeof(float) * (size_t)p * lda, st));
+    if (la_cols)
+        GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, lda, true, alpha, deg.p, shard_eig ? shard.row0 : 0u, la_cols));
+    GLF_TRY(dinv.alloc(ctx, p));
+    hipLaunchKernelGGL(k_dinv_from_degree, dim3((p + 255) / 256), dim3(256), 0, st, deg.p, p, alpha, dinv.p);
+    GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     // ---- eigenpairs --------------------------------------------------------------------------
     DevBuf<float> phiA;
@@ -324,8 +348,9 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     {
         std::vector<double> X0((size_t)m * p);
         glf_random_vectors(X0.data(), p, m, opt.seed);
-        int rc = inverse_power_iteration(ctx, LA.p, p32, p, m, ld, X0.data(), opt.opti_gs, opt.epsilon, opt.inner_rtol,
-                                         opt.max_outer > 0 ? opt.max_outer : 100000, phiA.p, lam.data(), &S.eig);
+        int rc = inverse_power_iteration(ctx, LA.p, lda, p, m, ld, X0.data(), opt.opti_gs, opt.epsilon, opt.inner_rtol,
+                                         opt.max_outer > 0 ? opt.max_outer : 100000, phiA.p, lam.data(), &S.eig,
+                                         shard_eig ? &shard : nullptr, dinv.p);
         if (rc != GLF_OK) return rc;
     }
     LA.release();

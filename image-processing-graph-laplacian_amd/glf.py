@@ -83,11 +83,12 @@ class Stats(C.Structure):
 
 ALLREDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLGATHER_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class Comm(C.Structure):
     _fields_ = [("rank", C.c_int), ("size", C.c_int), ("allreduce_sum_f32", ALLREDUCE_F32),
-                ("allreduce_sum_f64", ALLREDUCE_F64), ("user", C.c_void_p)]
+                ("allreduce_sum_f64", ALLREDUCE_F64), ("allgather_f32", ALLGATHER_F32), ("user", C.c_void_p)]
 
 
 _lib.glf_strerror.restype = C.c_char_p
@@ -188,35 +189,40 @@ def device_tensor_from_ptr(ptr, count, dtype, device):
     return torch.as_tensor(_Holder(), device=device)
 
 
-def make_comm(rank, size, allreduce):
-    """glf_comm whose callbacks call allreduce(ptr, count, is_f64) -> None (in place, sum over ranks).
-    Exceptions become a non-zero status (they cannot cross the C boundary). Keep the returned
-    struct alive for as long as the context uses it."""
-    def wrap(is_f64):
+def make_comm(rank, size, allreduce, allgather=None):
+    """glf_comm whose callbacks call allreduce(ptr, count, is_f64) and, if given,
+    allgather(ptr, count_per_rank) (both in place). Exceptions become a non-zero status (they cannot
+    cross the C boundary). Keep the returned struct alive for as long as the context uses it."""
+    def wrap(fn, *extra):
         def cb(user, ptr, count):
             try:
-                allreduce(ptr, count, is_f64)
+                fn(ptr, count, *extra)
                 return 0
             except Exception as exc:  # noqa: BLE001
-                print("glf allreduce callback failed:", repr(exc))
+                print("glf collective callback failed:", repr(exc))
                 return 1
         return cb
-    return Comm(rank, size, ALLREDUCE_F32(wrap(False)), ALLREDUCE_F64(wrap(True)), None)
+    ag = ALLGATHER_F32(wrap(allgather)) if allgather is not None else ALLGATHER_F32()
+    return Comm(rank, size, ALLREDUCE_F32(wrap(allreduce, False)), ALLREDUCE_F64(wrap(allreduce, True)), ag, None)
 
 
 # ---- device context --------------------------------------------------------------------
 
 class Context:
-    """One glf_ctx on one GPU, launching on torch's current stream of that device."""
+    """One glf_ctx on one GPU. The library launches on a dedicated torch stream (self.stream); the
+    collective callbacks run under that stream too, so RCCL / copies are ordered with the kernels.
+    (torch's default stream has handle 0, which the C-ABI reads as "create your own stream" -- a
+    private stream torch knows nothing about would race with the callbacks.)"""
 
-    def __init__(self, device=0, use_torch_stream=True):
+    def __init__(self, device=0):
         import torch
         self.torch = torch
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
+        self.stream = torch.cuda.Stream(device=self.device)
+        assert self.stream.cuda_stream != 0
         self._ctx = C.c_void_p()
-        rc = _lib.glf_ctx_create(C.byref(self._ctx), C.c_int(device), C.c_void_p(stream))
+        rc = _lib.glf_ctx_create(C.byref(self._ctx), C.c_int(device), C.c_void_p(self.stream.cuda_stream))
         if rc != OK:
             raise GlfError(rc, "glf_ctx_create(device=%d)" % device)
         self._comm_keepalive = None
@@ -250,7 +256,7 @@ class Context:
         return dict(name=name.value.decode(), num_cus=cus.value, total_mem=mem.value)
 
     # -- collectives ---------------------------------------------------------------------------
-    def set_comm_torch(self, group=None):
+    def set_comm_torch(self, group=None, shard_eigensolve=True):
         """Plug torch.distributed all-reduces into glf_comm: RCCL on the device buffers in place
         (backend "nccl"), or staged through host memory for a gloo group (CPU rehearsal of the
         N > 1 path, several ranks sharing one GPU in tests)."""
@@ -263,21 +269,39 @@ class Context:
         dev = self.device
         on_device = dist.get_backend(group) == "nccl"
 
-        def allreduce(ptr, count, is_f64):
-            t = device_tensor_from_ptr(ptr, count, torch.float64 if is_f64 else torch.float32, dev)
-            if on_device:
-                dist.all_reduce(t, group=group)
-            else:
-                h = t.cpu()
-                dist.all_reduce(h, group=group)
-                t.copy_(h)
+        stream = self.stream
 
-        self._comm_keepalive = make_comm(rank, size, allreduce)
+        def allreduce(ptr, count, is_f64):
+            with torch.cuda.stream(stream):   # ordered after the library's kernels, before its next ones
+                t = device_tensor_from_ptr(ptr, count, torch.float64 if is_f64 else torch.float32, dev)
+                if on_device:
+                    dist.all_reduce(t, group=group)
+                else:
+                    h = t.cpu()
+                    dist.all_reduce(h, group=group)
+                    t.copy_(h)
+                    stream.synchronize()      # h is pageable host memory
+
+        def allgather(ptr, count_per_rank):
+            with torch.cuda.stream(stream):
+                full = device_tensor_from_ptr(ptr, count_per_rank * size, torch.float32, dev)
+                mine = full[rank * count_per_rank:(rank + 1) * count_per_rank]
+                if on_device:
+                    dist.all_gather_into_tensor(full, mine, group=group)   # in place (RCCL allows it)
+                else:
+                    parts = [torch.empty(count_per_rank, dtype=torch.float32) for _ in range(size)]
+                    dist.all_gather(parts, mine.cpu(), group=group)
+                    full.copy_(torch.cat(parts))
+                    stream.synchronize()
+
+        self._comm_keepalive = make_comm(rank, size, allreduce, allgather if shard_eigensolve else None)
         self._check(_lib.glf_ctx_set_comm(self._ctx, C.byref(self._comm_keepalive)))
 
     # -- helpers ---------------------------------------------------------------------------
     def to_device(self, img):
-        t = self.torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(self.device)
+        with self.torch.cuda.stream(self.stream):
+            t = self.torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(self.device)
+        self.stream.synchronize()
         return t
 
     def mat_to_numpy(self, mat):
@@ -396,12 +420,14 @@ class Context:
     def ComputeResultFromLaplacian(self, d_img, phi, Pi, gain=3.0, want_float=True):
         torch = self.torch
         h, w = d_img.shape
-        out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
-        zf = torch.empty((h, w), dtype=torch.float32, device=self.device) if want_float else None
+        with torch.cuda.stream(self.stream):
+            out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+            zf = torch.empty((h, w), dtype=torch.float32, device=self.device) if want_float else None
         self._check(_lib.glf_ComputeResultFromLaplacian(
             self._ctx, C.c_void_p(d_img.data_ptr()), C.byref(phi), C.byref(Pi), C.c_uint(w), C.c_uint(h),
             C.c_float(gain), C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None),
             "ComputeResultFromLaplacian")
+        self.stream.synchronize()
         return out, zf
 
     def image_processing(self, d_img, opt=None, want_float=False, out=None):
@@ -410,15 +436,17 @@ class Context:
         assert d_img.dtype == torch.uint8 and d_img.is_cuda and d_img.dim() == 2 and d_img.is_contiguous()
         h, w = d_img.shape
         opt = opt or default_options()
-        if out is None:
-            out = torch.zeros((h, w), dtype=torch.uint8, device=self.device)
-        zf = torch.zeros((h, w), dtype=torch.float32, device=self.device) if want_float else None
+        with torch.cuda.stream(self.stream):   # the zero fills must be ordered before the library's writes
+            if out is None:
+                out = torch.zeros((h, w), dtype=torch.uint8, device=self.device)
+            zf = torch.zeros((h, w), dtype=torch.float32, device=self.device) if want_float else None
         st = Stats()
         lam = np.zeros(256, dtype=np.float64)
         rc = _lib.glf_image_processing(self._ctx, C.byref(opt), C.c_void_p(d_img.data_ptr()), C.c_int(w), C.c_int(h),
                                        C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None,
                                        lam.ctypes.data_as(C.c_void_p), C.byref(st))
         self._check(rc, "image_processing")
+        self.stream.synchronize()
         info = dict(p=st.p, m=st.m, alpha=st.alpha, outer_its=st.eig.outer_its,
                     inner_its_total=st.eig.inner_its_total, residual=st.eig.residual,
                     ms_affinity=st.ms_affinity, ms_laplacian=st.ms_laplacian, ms_eigen=st.ms_eigen,

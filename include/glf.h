@@ -72,6 +72,10 @@ typedef struct glf_comm {
     int rank, size;
     int (*allreduce_sum_f32)(void *user, float *dbuf, size_t count);
     int (*allreduce_sum_f64)(void *user, double *dbuf, size_t count);
+    /* In-place all-gather: dbuf holds size * count_per_rank floats, rank r's block at offset
+     * r * count_per_rank (replaces the allgather inside PETSc's MPIDENSE MatMult). Optional: with
+     * NULL the eigen-solve is replicated on every rank instead of row-sharded. */
+    int (*allgather_f32)(void *user, float *dbuf, size_t count_per_rank);
     void *user;
 } glf_comm;
 int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm);

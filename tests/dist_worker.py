@@ -31,6 +31,15 @@ def host_allreduce(ptr, count, is_f64):
     dist.all_reduce(t)
 
 
+def host_allgather(ptr, count_per_rank):
+    """In-place all-gather of a HOST float32 buffer through gloo."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(count_per_rank * world,))
+    parts = [torch.empty(count_per_rank, dtype=torch.float32) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(arr[rank * count_per_rank:(rank + 1) * count_per_rank].copy()))
+    arr[:] = torch.cat(parts).numpy()
+
+
 def run_cpu(out_path):
     import oracle as orc
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -41,6 +50,7 @@ def run_cpu(out_path):
     row0, row1 = glf.shard_rows(h, rank, world)
     # --- all-reduce #1: degree partial sums, through the C callback struct ---------------
     comm = glf.make_comm(rank, world, host_allreduce)
+    assert not comm.allgather_f32          # optional callback left NULL
     D = np.ascontiguousarray(orc.degree(img, idx, row0=row0, row1=row1))
     rc = comm.allreduce_sum_f64(None, D.ctypes.data_as(C.c_void_p), D.size)
     assert rc == 0
@@ -65,15 +75,24 @@ def run_cpu(out_path):
     # a failing callback must surface as a status, not as an exception through C
     bad = glf.make_comm(rank, world, lambda *a: (_ for _ in ()).throw(RuntimeError("boom")))
     assert bad.allreduce_sum_f64(None, c64.ctypes.data_as(C.c_void_p), c64.size) == 1
+    # row-sharded mat-vec plumbing: each rank fills its block of Y = L_A X, the in-place
+    # all-gather callback completes it on every rank (how the sharded eigen-solve uses glf_comm)
+    comm2 = glf.make_comm(rank, world, host_allreduce, host_allgather)
+    p = idx.size
+    rpr = -(-(-(-p // world)) // 64) * 64
+    Y = np.zeros((rpr * world, m), dtype=np.float32)
+    r0, r1 = min(rank * rpr, p), min((rank + 1) * rpr, p)
+    Y[r0:r1] = (LA[r0:r1] @ vecs.T).astype(np.float32)
+    assert comm2.allgather_f32(None, Y.ctypes.data_as(C.c_void_p), rpr * m) == 0
     np.savez(out_path % rank, D=D, c64=c64, c32=c32, z=z_local, rows=np.array([row0, row1]),
-             outer=st["outer_its"])
+             outer=st["outer_its"], Y=Y[:p], Yref=(LA @ vecs.T).astype(np.float32))
 
 
-def run_gpu(out_path):
+def run_gpu(out_path, shard_eigensolve=True):
     rank = dist.get_rank()
     img = glf.synth_image(96, 80, seed=4)
     with glf.Context(0) as ctx:
-        ctx.set_comm_torch()
+        ctx.set_comm_torch(shard_eigensolve=shard_eigensolve)
         opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
         out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
         np.savez(out_path % rank, out=out.cpu().numpy(), zf=zf.cpu().numpy(), rows=np.array([info["row0"], info["row1"]]),
@@ -84,7 +103,10 @@ if __name__ == "__main__":
     mode, out_path = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     try:
-        (run_cpu if mode == "cpu" else run_gpu)(out_path)
+        if mode == "cpu":
+            run_cpu(out_path)
+        else:
+            run_gpu(out_path, shard_eigensolve=(mode == "gpu"))
     finally:
         dist.barrier()
         dist.destroy_process_group()

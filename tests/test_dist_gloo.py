@@ -76,14 +76,19 @@ def test_two_rank_gloo_cpu(tmp_path):
     z = np.concatenate([r[0]["z"], r[1]["z"]]).reshape(h, w)
     np.testing.assert_allclose(z, zf_ref, rtol=0, atol=1e-8)
     np.testing.assert_allclose(r[0]["c32"], r[0]["c64"], rtol=1e-5)
+    for k in range(2):   # all-gathered mat-vec complete and identical on both ranks
+        np.testing.assert_array_equal(r[k]["Y"], r[k]["Yref"])
 
 
 @pytest.mark.gpu
-def test_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["gpu", "gpu_replicated"])
+def test_two_ranks_share_one_gpu(tmp_path, mode):
+    """mode gpu: L_A column-sharded, mat-vec rows all-gathered; gpu_replicated: no allgather
+    callback, every rank solves the whole eigenproblem. Both must reproduce the single-rank run."""
     import torch
     assert torch.cuda.is_available()
     pattern = str(tmp_path / "gpu_rank%d.npz")
-    _launch("gpu", pattern, timeout=600)
+    _launch(mode, pattern, timeout=600)
     r = [np.load(pattern % k) for k in range(2)]
     img = glf.synth_image(96, 80, seed=4)
     h, w = img.shape
