@@ -179,7 +179,8 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float scale, const float *d_psi, unsigned m, unsigned ld,
-                      float *d_phi, int raster, double *d_c, float *kernel_ms);
+                      float *d_phi, int raster, double *d_c, float *kernel_ms, int window = 0,
+                      uint64_t *chunks_visited = nullptr);
 // Phi rows of the sample pixels <- Phi_A rows (hpc/nystroem.c:25-34 + hpc/utils.c:149-152)
 int scatter_sample_rows(glf_ctx *ctx, const float *d_phiA, unsigned p, unsigned ld, const uint32_t *d_idx,
                         float *d_phi, int raster, const uint8_t *d_img, double *d_c, unsigned m);

@@ -34,16 +34,78 @@ __device__ __forceinline__ unsigned samples_before(const uint32_t *__restrict__ 
     return lo;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Exact-zero skipping. A sample whose row or column distance to every pixel of the workgroup
+// exceeds `radius` has exp2(-t) below the smallest value the contraction can represent (radius is
+// chosen on the host from the arithmetic in use), so its whole chunk of 64 samples contributes
+// exactly +0 to every accumulator: skipping it leaves the output bit-identical. Each workgroup
+// compacts, in ascending order (accumulation order is preserved), the chunks whose bounding box
+// comes within `radius` of its pixels' bounding box.
+// ---------------------------------------------------------------------------------------------
+constexpr int NYS_MAXCH = 4096; // chunks a workgroup can list (p <= 262 144); more -> dense on the host side
+
+// box[chunk] = {rmin, rmax, cmin, cmax} over the chunk's valid samples
+__global__ void k_chunk_boxes(const float4 *__restrict__ samples, unsigned p, int4 *__restrict__ box)
+{
+    const unsigned ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch * 64 >= p) return;
+    int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
+    for (unsigned s = ch * 64; s < min(ch * 64 + 64, p); ++s) {
+        const float4 v = samples[s];
+        rmin = min(rmin, (int)v.x);
+        rmax = max(rmax, (int)v.x);
+        cmin = min(cmin, (int)v.y);
+        cmax = max(cmax, (int)v.y);
+    }
+    box[ch] = make_int4(rmin, rmax, cmin, cmax);
+}
+
+// Returns the number of listed chunks (all of them, identity order, when radius < 0).
+__device__ __forceinline__ int build_chunk_list(const int4 *__restrict__ box, int nchunks, int radius, int width,
+                                                int64_t wg_first, int64_t wg_last, int *clist, int *scratch /* [257] */)
+{
+    if (radius < 0) return nchunks;
+    const int t = threadIdx.x;
+    const int r_lo = (int)(wg_first / width), r_hi = (int)(wg_last / width);
+    const int c_lo = (r_lo == r_hi) ? (int)(wg_first % width) : 0;
+    const int c_hi = (r_lo == r_hi) ? (int)(wg_last % width) : width - 1;
+    const int per = (nchunks + 255) / 256;
+    unsigned bits = 0;
+    int count = 0;
+    for (int i = 0; i < per; ++i) {
+        const int ch = t * per + i;
+        if (ch < nchunks) {
+            const int4 b = box[ch];
+            const bool rel = b.y >= r_lo - radius && b.x <= r_hi + radius && b.w >= c_lo - radius && b.z <= c_hi + radius;
+            bits |= (unsigned)rel << i;
+            count += rel;
+        }
+    }
+    scratch[t] = count;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < t; ++k) off += scratch[k];
+    if (t == 255) scratch[256] = off + count;
+    for (int i = 0; i < per; ++i)
+        if (bits & (1u << i)) clist[off++] = t * per + i;
+    __syncthreads();
+    return scratch[256];
+}
+
 template <int MB, int PB> // MB = ld / 32 column blocks; PB = 32-pixel blocks per wave
 __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ img, int width, int64_t pix0, int64_t pix1,
                                                    const float4 *__restrict__ samples, unsigned p, float s_loc,
                                                    float s_val, const float *__restrict__ psi,
                                                    float *__restrict__ phi, int raster,
                                                    const uint8_t *__restrict__ mask, const uint32_t *__restrict__ idx,
-                                                   double *__restrict__ cpartial)
+                                                   double *__restrict__ cpartial, const int4 *__restrict__ chunk_box,
+                                                   int radius, unsigned *__restrict__ visited)
 {
     constexpr int LD = MB * 32;
     constexpr int KC = NYS_KC;
+    __shared__ int clist[NYS_MAXCH];
+    __shared__ int cscratch[257];
     // one array for everything (guide: a second __shared__ object can de-pipeline LDS staging)
     __shared__ __attribute__((aligned(16))) float lds[2 * (NYS_KC * 4 + NYS_KC * MB * 32)];
     constexpr int BUF = KC * 4 + KC * LD; // floats per buffer: sample table then Psi tile
@@ -72,6 +134,11 @@ __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ im
             for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
 
     const int nchunks = (int)((p + KC - 1) / KC);
+    const int64_t wg_first = pix0 + (int64_t)blockIdx.x * (128 * PB);
+    const int64_t wg_last = min(wg_first + 128 * PB, pix1) - 1;
+    const int nlist = build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch);
+    if (visited && threadIdx.x == 0) visited[blockIdx.x] = (unsigned)nlist;
+    auto chunk_at = [&](int i) { return radius < 0 ? i : clist[i]; };
     auto stage = [&](int chunk, int buf) {
         const unsigned s0 = (unsigned)chunk * KC;
         if (threadIdx.x < KC) {
@@ -85,11 +152,11 @@ __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ im
             *reinterpret_cast<float4 *>(lds + buf * BUF + KC * 4 + e) = v;
         }
     };
-    stage(0, 0);
+    if (nlist > 0) stage(chunk_at(0), 0);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = 0; ch < nlist; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+        if (ch + 1 < nlist) stage(chunk_at(ch + 1), buf ^ 1);
         const float4 *stb = reinterpret_cast<const float4 *>(lds + buf * BUF) + half * (KC / 2);
         const float *psb = lds + buf * BUF + KC * 4 + (half * (KC / 2)) * LD + l31;
 #pragma unroll 4
@@ -194,21 +261,58 @@ static int sum_rows(glf_ctx *ctx, const double *d_in, int64_t nrows, unsigned ld
     return GLF_OK;
 }
 
+// Host side of the exact-zero skipping: radius from the contraction's arithmetic, chunk boxes, and
+// the per-workgroup "chunks visited" counters (summed for the executed-work accounting).
+struct NysWindow {
+    DevBuf<int4> box;
+    DevBuf<unsigned> visited;
+    int radius = -1;
+    int init(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef, int window, double t_zero, int64_t nwg)
+    {
+        const unsigned nchunks = (unsigned)ceil_div(p, 64);
+        radius = -1;
+        // K < 2^-t_zero is exactly zero for the contraction; t >= s_loc * d^2 for a row or column distance d
+        if (window && coef.s_loc > 0.f && nchunks <= (unsigned)NYS_MAXCH)
+            radius = (int)std::floor(std::sqrt(t_zero / (double)coef.s_loc)) + 1;
+        GLF_TRY(box.alloc(ctx, nchunks));
+        GLF_TRY(visited.alloc(ctx, (size_t)nwg));
+        hipLaunchKernelGGL(k_chunk_boxes, dim3((nchunks + 63) / 64), dim3(64), 0, ctx->stream, d_samples, p, box.p);
+        GLF_LAUNCH_CHECK(ctx);
+        return GLF_OK;
+    }
+    int total(glf_ctx *ctx, int64_t nwg, uint64_t *out)
+    {
+        std::vector<unsigned> h((size_t)nwg);
+        GLF_HIP(ctx, hipMemcpyAsync(h.data(), visited.p, sizeof(unsigned) * (size_t)nwg, hipMemcpyDeviceToHost, ctx->stream));
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t s = 0;
+        for (unsigned v : h) s += v;
+        *out = s;
+        return GLF_OK;
+    }
+};
+
 template <int MB, int PB>
 static int launch_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int64_t pix0, int64_t pix1,
                            const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
-                           KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms)
+                           KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms,
+                           int window, uint64_t *chunks_visited)
 {
     constexpr int LD = MB * 32;
     const int64_t npix = pix1 - pix0;
     const int64_t nwg = ceil_div(npix, 4 * 32 * PB);
     DevBuf<double> cpart;
     if (d_c) GLF_TRY(cpart.alloc(ctx, (size_t)nwg * LD));
+    // f32 operands: K underflows to exactly 0 below 2^-149 (t > 150)
+    NysWindow win;
+    GLF_TRY(win.init(ctx, d_samples, p, coef, window, 151.0, nwg));
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     hipLaunchKernelGGL((k_nystroem<MB, PB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, d_img, width, pix0, pix1,
-                       d_samples, p, coef.s_loc, coef.s_val, d_psi, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr);
+                       d_samples, p, coef.s_loc, coef.s_val, d_psi, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
+                       win.box.p, win.radius, win.visited.p);
     GLF_LAUNCH_CHECK(ctx);
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (chunks_visited) GLF_TRY(win.total(ctx, nwg, chunks_visited));
     if (d_c) GLF_TRY(sum_rows(ctx, cpart.p, nwg, LD, d_c, true));
     if (kernel_ms) {
         GLF_HIP(ctx, hipEventSynchronize(ctx->ev[7]));
@@ -287,9 +391,12 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                                                         const _Float16 *__restrict__ psi16, const float *__restrict__ invscale,
                                                         float *__restrict__ phi, int raster,
                                                         const uint8_t *__restrict__ mask, const uint32_t *__restrict__ idx,
-                                                        double *__restrict__ cpartial)
+                                                        double *__restrict__ cpartial, const int4 *__restrict__ chunk_box,
+                                                        int radius, unsigned *__restrict__ visited)
 {
     constexpr int LD = MB * 32;
+    __shared__ int clist[NYS_MAXCH];
+    __shared__ int cscratch[257];
     constexpr int PSI_F4 = 4 * MB * 2 * 64;      // float4 (16 B) words of one chunk's Psi fragments
     constexpr int NV = PSI_F4 / 256;             // per thread
     constexpr int BUF_F4 = 64 + PSI_F4;          // + 1 KiB sample SoA
@@ -317,6 +424,11 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
             for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
 
     const int nchunks = (int)((p + 63) / 64);
+    const int64_t wg_first = pix0 + (int64_t)blockIdx.x * (128 * PB);
+    const int64_t wg_last = min(wg_first + 128 * PB, pix1) - 1;
+    const int nlist = build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch);
+    if (visited && threadIdx.x == 0) visited[blockIdx.x] = (unsigned)nlist;
+    auto chunk_at = [&](int i) { return radius < 0 ? i : clist[i]; };
     const float4 *gsoa = reinterpret_cast<const float4 *>(soa);
     const float4 *gpsi = reinterpret_cast<const float4 *>(psi16);
     float4 stage_s, stage_p[NV];
@@ -331,12 +443,14 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
 #pragma unroll
         for (int v = 0; v < NV; ++v) dst[64 + v * 256 + threadIdx.x] = stage_p[v];
     };
-    g_load(0);
-    l_store(0);
+    if (nlist > 0) {
+        g_load(chunk_at(0));
+        l_store(0);
+    }
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = 0; ch < nlist; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunks) g_load(ch + 1); // in flight during the MFMA/VALU sweep below
+        if (ch + 1 < nlist) g_load(chunk_at(ch + 1)); // in flight during the MFMA/VALU sweep below
         const float *ssoa = reinterpret_cast<const float *>(lds + buf * BUF_F4);
         const f16x8 *sfrag = reinterpret_cast<const f16x8 *>(lds + buf * BUF_F4 + 64);
 #pragma unroll
@@ -383,7 +497,7 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                 }
             }
         }
-        if (ch + 1 < nchunks) l_store(buf ^ 1);
+        if (ch + 1 < nlist) l_store(buf ^ 1);
         __syncthreads();
     }
 
@@ -436,7 +550,8 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
 template <int MB, int PB>
 static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, int64_t pix0, int64_t pix1,
                                 const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
-                                KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms)
+                                KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms,
+                                int window, uint64_t *chunks_visited)
 {
     constexpr unsigned LD = MB * 32;
     const unsigned p_pad = (unsigned)round_up(p, NYS_PAD);
@@ -476,11 +591,16 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     const int64_t nwg = ceil_div(npix, 4 * 32 * PB);
     DevBuf<double> cpart;
     if (d_c) GLF_TRY(cpart.alloc(ctx, (size_t)nwg * LD));
+    // K' = 2^15 K rounds to zero in f16 (hi and lo) below 2^-25: t > 40; 40.5 covers the f32 rounding of t
+    NysWindow win;
+    GLF_TRY(win.init(ctx, d_samples, p, coef, window, 40.5, nwg));
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[6], st));
     hipLaunchKernelGGL((k_nystroem_f16s<MB, PB>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
-                       coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr);
+                       coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
+                       win.box.p, win.radius, win.visited.p);
     GLF_LAUNCH_CHECK(ctx);
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], st));
+    if (chunks_visited) GLF_TRY(win.total(ctx, nwg, chunks_visited));
     if (d_c) GLF_TRY(sum_rows(ctx, cpart.p, nwg, LD, d_c, true));
     GLF_HIP(ctx, hipStreamSynchronize(st)); // hscale/hinv and the DevBufs go out of scope
     if (kernel_ms) GLF_HIP(ctx, hipEventElapsedTime(kernel_ms, ctx->ev[6], ctx->ev[7]));
@@ -490,7 +610,7 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float /*scale folded into psi*/, const float *d_psi, unsigned m, unsigned ld,
-                      float *d_phi, int raster, double *d_c, float *kernel_ms)
+                      float *d_phi, int raster, double *d_c, float *kernel_ms, int window, uint64_t *chunks_visited)
 {
     const int64_t N = (int64_t)width * height;
     if (pix0 < 0 || pix1 > N || pix0 > pix1 || !valid_ld(ld) || m > ld)
@@ -499,22 +619,22 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
     if (pix0 == pix1) return GLF_OK;
     if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
         switch (ld) {
-        case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
-        case 64: return launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
-        case 128: return launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
-        case 256: return launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        case 64: return launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        case 128: return launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        case 256: return launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
         }
         return GLF_ERR_UNSUPPORTED;
     }
     switch (ld) {
     case 32:
-        return launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        return launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
     case 64:
-        return launch_nystroem<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        return launch_nystroem<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
     case 128:
-        return launch_nystroem<4, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        return launch_nystroem<4, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
     case 256:
-        return launch_nystroem<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms);
+        return launch_nystroem<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
     }
     return GLF_ERR_UNSUPPORTED;
 }

@@ -68,6 +68,7 @@ class Options(C.Structure):
         ("num_eigvals", C.c_uint32), ("opti_gs", C.c_int32), ("epsilon", C.c_double),
         ("inner_rtol", C.c_double), ("max_outer", C.c_int32), ("seed", C.c_uint64), ("gain", C.c_float),
         ("h_loc", C.c_float), ("h_val", C.c_float), ("kernel", C.c_int32), ("filter_pow", C.c_int32),
+        ("skip_exact_zeros", C.c_int32),
     ]
 
 
@@ -77,7 +78,8 @@ class Stats(C.Structure):
         ("ms_affinity", C.c_float), ("ms_laplacian", C.c_float), ("ms_eigen", C.c_float),
         ("ms_nystroem", C.c_float), ("ms_filter", C.c_float), ("ms_total", C.c_float),
         ("nystroem_launches", C.c_int32), ("nystroem_kernel_ms", C.c_float),
-        ("row0", C.c_int32), ("row1", C.c_int32),
+        ("row0", C.c_int32), ("row1", C.c_int32), ("contraction", C.c_int32), ("skip_exact_zeros", C.c_int32),
+        ("nystroem_evaluated", C.c_double), ("degree_evaluated", C.c_double),
     ]
 
 
@@ -452,5 +454,7 @@ class Context:
                     ms_affinity=st.ms_affinity, ms_laplacian=st.ms_laplacian, ms_eigen=st.ms_eigen,
                     ms_nystroem=st.ms_nystroem, ms_filter=st.ms_filter, ms_total=st.ms_total,
                     nystroem_kernel_ms=st.nystroem_kernel_ms, nystroem_launches=st.nystroem_launches,
-                    row0=st.row0, row1=st.row1, eigvals=lam[:st.m].copy())
+                    row0=st.row0, row1=st.row1, contraction=st.contraction, skip_exact_zeros=st.skip_exact_zeros,
+                    nystroem_evaluated=st.nystroem_evaluated, degree_evaluated=st.degree_evaluated,
+                    eigvals=lam[:st.m].copy())
         return out, zf, info

@@ -226,6 +226,10 @@ typedef struct glf_options {
     float h_loc, h_val;     /* 40, 30 hpc/affinity.c:117-118 */
     int32_t kernel;         /* GLF_KERNEL_BILATERAL */
     int32_t filter_pow;     /* 1: f(Pi) = Pi (MatPow is a no-op, hpc/utils.c:721); k: Pi^k */
+    int32_t skip_exact_zeros; /* 0 (default): every K_B / K_A entry is evaluated, as the reference does.
+                                 1: entries that are exactly zero in the arithmetic in use (pixel-sample
+                                 distance beyond the radius where exp underflows) are skipped in whole tiles;
+                                 the output is bit-identical, the work is not -- see glf_stats.*_evaluated. */
 } glf_options;
 void glf_options_default(glf_options *opt);
 
@@ -239,6 +243,10 @@ typedef struct glf_stats {
     int32_t nystroem_launches;
     float nystroem_kernel_ms;
     int32_t row0, row1;     /* this rank's pixel rows */
+    int32_t contraction;    /* GLF_CONTRACT_* actually used */
+    int32_t skip_exact_zeros;
+    /* kernel evaluations actually executed by this rank (dense: p * pixels of the rank) */
+    double nystroem_evaluated, degree_evaluated;
 } glf_stats;
 
 /* ApproximationComputation, hpc/image_processing.c:183-277 (commented tail

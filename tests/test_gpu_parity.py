@@ -358,3 +358,25 @@ def test_errors_are_loud(ctx):
     out, _, info = ctx.image_processing(d_img, glf.default_options(num_samples=12, num_eigvals=1000))
     assert info["m"] == info["p"] - 1       # num_eigvals >= p -> p - 1 (hpc/image_processing.c:96-108)
     assert out.dtype == torch.uint8
+
+
+def test_exact_zero_skipping_is_bit_identical(ctx):
+    """glf_options.skip_exact_zeros drops whole 64-sample chunks whose kernel entries are exactly zero
+    in the arithmetic in use; the result must not change by a single bit, only the executed work."""
+    import torch
+    img = glf.synth_image(1280, 1024, seed=11)
+    d_img = ctx.to_device(img)
+    ns = int(1280 * 1024 * 0.005)
+    res = {}
+    for skip in (0, 1):
+        opt = glf.default_options(num_samples=ns, num_eigvals=32, epsilon=0.1, skip_exact_zeros=skip)
+        out, zf, info = ctx.image_processing(d_img, opt, want_float=True)
+        res[skip] = (out.clone(), zf.clone(), info)
+    (o0, z0, i0), (o1, z1, i1) = res[0], res[1]
+    assert i0["skip_exact_zeros"] == 0 and i1["skip_exact_zeros"] == 1
+    assert torch.equal(o0, o1)
+    assert torch.equal(z0.view(torch.int32), z1.view(torch.int32))      # bit for bit
+    np.testing.assert_array_equal(i0["eigvals"], i1["eigvals"])
+    dense = float(i0["p"]) * 1280 * 1024
+    assert i0["nystroem_evaluated"] == pytest.approx(dense, rel=0.02)    # chunk padding only
+    assert i1["nystroem_evaluated"] < 0.8 * i0["nystroem_evaluated"]
