@@ -6,6 +6,9 @@
 // stored: 5.3 TiB at 4096^2 / 0.5 %.
 #include "glf_internal.hpp"
 
+#include <algorithm>
+#include <cmath>
+
 namespace glf {
 
 // ---- sample tables ------------------------------------------------------------------
@@ -163,6 +166,122 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
                        d_degree);
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream)); // partial is freed at scope exit
+    return GLF_OK;
+}
+
+// ---- degree with exact-zero skipping -----------------------------------------------------------
+// exp2(-t) underflows to exactly 0 in f32 once s_loc * d^2 > 150 for a row or column distance d, so a
+// block of 256 spatially compact samples only needs the pixels within `radius` of its bounding box; the
+// rest would add +0 (or denormals that cannot change a sum >= 1). Samples are taken in a tile-major
+// order (perm) so that a block is compact in both directions. Same accumulation structure as k_degree.
+__global__ __launch_bounds__(DEG_THREADS) void k_degree_win(const uint8_t *__restrict__ img, int width, int row0, int row1,
+                                                             int rows_per_chunk, const float4 *__restrict__ samples,
+                                                             unsigned p, const uint32_t *__restrict__ perm,
+                                                             const int4 *__restrict__ blk_box, int radius, float s_loc,
+                                                             float s_val, double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float rowv[DEG_MAXW];
+    const uint32_t i = perm[blockIdx.x * DEG_THREADS + threadIdx.x]; // 0xFFFFFFFF = padding
+    const bool live = i < p;
+    const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int4 box = blk_box[blockIdx.x]; // {rmin, rmax, cmin, cmax} of the block's samples
+    const int rw0 = max(row0, box.x - radius), rw1 = min(row1, box.y + radius + 1);
+    const int cw0 = max(0, box.z - radius) & ~3, cw1 = min(width, box.w + radius + 1);
+    const int r_begin = rw0 + (int)blockIdx.y * rows_per_chunk;
+    const int r_end = min(r_begin + rows_per_chunk, rw1);
+    double total = 0.0;
+    for (int r = r_begin; r < r_end; ++r) { // r_begin >= r_end: nothing to do, partial = 0
+        const float dr = s.x - (float)r;
+        const float a = dr * dr * s_loc;
+        for (int c0 = cw0; c0 < cw1; c0 += DEG_MAXW) {
+            const int seg = min(DEG_MAXW, cw1 - c0);
+            const int seg4 = (seg + 3) & ~3;
+            __syncthreads();
+            for (int c = threadIdx.x; c < seg4; c += DEG_THREADS)
+                rowv[c] = (c < seg) ? (float)img[(size_t)r * width + c0 + c] : 0.f;
+            __syncthreads();
+            float acc = 0.f;
+            float dc = s.y - (float)c0;
+            const int full4 = seg & ~3;
+            for (int c = 0; c < full4; c += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&rowv[c]);
+                const float pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dv = s.z - pv[u];
+                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                    acc += __builtin_amdgcn_exp2f(-t);
+                    dc -= 1.f;
+                }
+            }
+            for (int c = full4; c < seg; ++c) {
+                const float dv = s.z - rowv[c];
+                const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
+                acc += __builtin_amdgcn_exp2f(-t);
+                dc -= 1.f;
+            }
+            total += (double)acc;
+        }
+    }
+    if (live) partial[(size_t)blockIdx.y * p + i] = total;
+}
+
+int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
+                         const float4 *d_samples, unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree,
+                         double *evaluated)
+{
+    if (row0 < 0 || row1 > height || row0 > row1) return set_error(ctx, GLF_ERR_INVALID, "bad row range");
+    if (evaluated) *evaluated = 0.0;
+    if (row0 == row1) {
+        GLF_HIP(ctx, hipMemsetAsync(d_degree, 0, sizeof(double) * p, ctx->stream));
+        return GLF_OK;
+    }
+    const int radius = (int)std::floor(std::sqrt(151.0 / (double)coef.s_loc)) + 1; // t > 150 => exp2(-t) == 0 in f32
+    // tile-major sample order: tiles of about 256 samples
+    const int64_t N = (int64_t)width * height;
+    const int tile = std::max(8, (int)std::ceil(16.0 * std::sqrt((double)N / (double)p)));
+    const int ntc = (int)ceil_div(width, tile);
+    std::vector<uint32_t> perm(p);
+    for (unsigned i = 0; i < p; ++i) perm[i] = i;
+    std::vector<uint32_t> key(p);
+    for (unsigned i = 0; i < p; ++i) key[i] = (uint32_t)((h_idx[i] / (unsigned)width) / (unsigned)tile * (unsigned)ntc + (h_idx[i] % (unsigned)width) / (unsigned)tile);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    const int nsb = (int)ceil_div(p, DEG_THREADS);
+    perm.resize((size_t)nsb * DEG_THREADS, 0xFFFFFFFFu);
+    std::vector<int4> box(nsb);
+    int max_rows = 1;
+    double evals = 0.0;
+    for (int b = 0; b < nsb; ++b) {
+        int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
+        for (int t = 0; t < DEG_THREADS; ++t) {
+            const uint32_t i = perm[(size_t)b * DEG_THREADS + t];
+            if (i >= p) continue;
+            const int r = (int)(h_idx[i] / (unsigned)width), c = (int)(h_idx[i] % (unsigned)width);
+            rmin = std::min(rmin, r); rmax = std::max(rmax, r); cmin = std::min(cmin, c); cmax = std::max(cmax, c);
+        }
+        box[b] = make_int4(rmin, rmax, cmin, cmax);
+        const int rows = std::max(0, std::min(row1, rmax + radius + 1) - std::max(row0, rmin - radius));
+        const int cols = std::min(width, cmax + radius + 1) - (std::max(0, cmin - radius) & ~3);
+        max_rows = std::max(max_rows, rows);
+        evals += (double)DEG_THREADS * rows * cols;
+    }
+    if (evaluated) *evaluated = evals;
+    const int rows_per_chunk = 16;
+    const int nchunks = (int)ceil_div(max_rows, rows_per_chunk);
+    DevBuf<uint32_t> d_perm;
+    DevBuf<int4> d_box;
+    DevBuf<double> partial;
+    GLF_TRY(d_perm.alloc(ctx, perm.size()));
+    GLF_TRY(d_box.alloc(ctx, box.size()));
+    GLF_TRY(partial.alloc(ctx, (size_t)nchunks * p));
+    GLF_HIP(ctx, hipMemcpyAsync(d_perm.p, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice, ctx->stream));
+    GLF_HIP(ctx, hipMemcpyAsync(d_box.p, box.data(), sizeof(int4) * box.size(), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_degree_win, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, ctx->stream, d_img, width, row0, row1,
+                       rows_per_chunk, d_samples, p, d_perm.p, d_box.p, radius, coef.s_loc, coef.s_val, partial.p);
+    GLF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks, d_degree);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream)); // host vectors and DevBufs are released at scope exit
     return GLF_OK;
 }
 

@@ -135,6 +135,12 @@ int build_sample_tables(glf_ctx *ctx, const uint8_t *d_img, int width, int heigh
 int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
                 const float4 *d_samples, unsigned p, KernelCoef coef, double *d_degree);
 
+// Same sums, skipping pixels whose kernel entry underflows to exactly 0 in f32 for every sample of a block
+// (h_idx: host sample indices, needed for the tile-major sample order). evaluated: entries executed.
+int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
+                         const float4 *d_samples, unsigned p, const unsigned *h_idx, KernelCoef coef,
+                         double *d_degree, double *evaluated);
+
 // K_A (scale = 1, diag untouched) or L_A (scale = -alpha, diagonal alpha * D_i).
 // columns [col0, col0 + ncols) only (ncols = 0: all p columns); out is [p][ld] with local column index
 int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef,

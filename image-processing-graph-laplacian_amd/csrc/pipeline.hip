@@ -311,7 +311,13 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     GLF_TRY(build_sample_tables(ctx, d_img, width, height, p, h_idx, tb));
     DevBuf<double> deg;
     GLF_TRY(deg.alloc(ctx, p));
-    GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
+    if (opt.skip_exact_zeros && coef.s_loc > 0.f) {
+        GLF_TRY(degree_rows_windowed(ctx, d_img, width, height, row0, row1, tb.samples.p, p, h_idx, coef, deg.p,
+                                     &S.degree_evaluated));
+    } else {
+        GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
+        S.degree_evaluated = (double)p * (double)(pix1 - pix0);
+    }
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     // ---- Laplacian ---------------------------------------------------------------------------

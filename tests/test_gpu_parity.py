@@ -380,3 +380,6 @@ def test_exact_zero_skipping_is_bit_identical(ctx):
     dense = float(i0["p"]) * 1280 * 1024
     assert i0["nystroem_evaluated"] == pytest.approx(dense, rel=0.02)    # chunk padding only
     assert i1["nystroem_evaluated"] < 0.8 * i0["nystroem_evaluated"]
+    assert i0["degree_evaluated"] == dense
+    assert i1["degree_evaluated"] < 0.9 * dense
+    assert i0["alpha"] == i1["alpha"]                                    # D_A identical to the last bit
