@@ -112,6 +112,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int MV_ASCALE_LOG2 = 10;
+constexpr int MV_MAXTILES = 4096; // K tiles a workgroup can list (p <= 262 144)
 
 __global__ void k_mv_col_absmax(const float *__restrict__ X, unsigned p, unsigned ld, float *__restrict__ out)
 {
@@ -166,12 +167,15 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
                                                             unsigned p_pad, unsigned row_begin, unsigned row_end,
                                                             const _Float16 *__restrict__ xfrag,
                                                             const float *__restrict__ scales, float *__restrict__ Y,
-                                                            float *__restrict__ Ypart)
+                                                            float *__restrict__ Ypart, const int4 *__restrict__ kbox,
+                                                            int radius, int nslabs)
 {
     constexpr int LD = MB * 32;
     constexpr int FR_F4 = 4 * MB * 2 * 64; // float4 words of one K tile's X fragments
     constexpr int NV = FR_F4 / 256;
     __shared__ __attribute__((aligned(16))) float4 lds[2 * FR_F4];
+    __shared__ int tlist[MV_MAXTILES];
+    __shared__ int tscratch[257];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const unsigned rbase = row_begin + blockIdx.x * 128 + wave * 32;
@@ -189,8 +193,40 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
     // K split: blockIdx.y sweeps tiles [kt_begin, kt_end); with gridDim.y > 1 the partial sums go to
     // slab blockIdx.y of Ypart and k_mv_sum_splits adds them in fixed order.
     const int ntiles = p_pad / 64;
-    const int kt_begin = (int)((int64_t)ntiles * blockIdx.y / gridDim.y);
-    const int kt_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / gridDim.y);
+    // tiles this workgroup's 128 rows actually need (all of them when radius < 0), in ascending order
+    int nlist = ntiles;
+    if (radius >= 0) {
+        const unsigned blk0 = row_begin + blockIdx.x * 128;       // multiple of 64
+        const unsigned blk1 = min(blk0 + 128, row_end);
+        int4 rb = kbox[blk0 / 64];
+        if (blk0 + 64 < blk1) {
+            const int4 b2 = kbox[blk0 / 64 + 1];
+            rb = make_int4(min(rb.x, b2.x), max(rb.y, b2.y), min(rb.z, b2.z), max(rb.w, b2.w));
+        }
+        const int t = threadIdx.x, per = (ntiles + 255) / 256;
+        const int nvalid = (int)((p + 63) / 64); // tiles past the last sample hold nothing
+        unsigned bits = 0;
+        int count = 0;
+        for (int i = 0; i < per; ++i) {
+            const int kt = t * per + i;
+            if (kt < nvalid) {
+                const int4 b = kbox[kt];
+                const bool rel = b.y >= rb.x - radius && b.x <= rb.y + radius && b.w >= rb.z - radius && b.z <= rb.w + radius;
+                bits |= (unsigned)rel << i;
+                count += rel;
+            }
+        }
+        tscratch[t] = count;
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < t; ++k) off += tscratch[k];
+        if (t == 255) tscratch[256] = off + count;
+        for (int i = 0; i < per; ++i)
+            if (bits & (1u << i)) tlist[off++] = t * per + i;
+        __syncthreads();
+        nlist = tscratch[256];
+    }
+    auto tile_at = [&](int i) { return radius < 0 ? i : tlist[i]; };
     float a_cur[32], a_nxt[32];
     float4 xs[NV];
     auto load_a = [&](int kt, float (&dst)[32]) {
@@ -206,51 +242,88 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
             }
         }
     };
-    if (kt_begin < kt_end) {
-        load_a(kt_begin, a_cur);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) lds[v * 256 + threadIdx.x] = gfr[(size_t)kt_begin * FR_F4 + v * 256 + threadIdx.x];
-    }
-    __syncthreads();
     const float ascale = (float)(1 << MV_ASCALE_LOG2);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) {
-            load_a(kt + 1, a_nxt);
+    // acc += sum over list entries [lb, le): prologue + double-buffered sweep
+    auto sweep = [&](int lb, int le) {
+        __syncthreads(); // LDS buffers of a previous sweep are free
+        if (lb < le) {
+            const int kt0 = tile_at(lb);
+            load_a(kt0, a_cur);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) xs[v] = gfr[(size_t)(kt + 1) * FR_F4 + v * 256 + threadIdx.x];
-        }
-        const f16x8 *fr = reinterpret_cast<const f16x8 *>(lds + buf * FR_F4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f16x8 ah, al;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                f32x2 y = {a_cur[8 * t + e] * ascale, a_cur[8 * t + e + 1] * ascale};
-                const f16x2 h2 = __builtin_convertvector(y, f16x2);
-                const f32x2 res = y - __builtin_convertvector(h2, f32x2);
-                const f16x2 l2 = __builtin_convertvector(res, f16x2);
-                ah[e] = h2[0];
-                ah[e + 1] = h2[1];
-                al[e] = l2[0];
-                al[e + 1] = l2[1];
-            }
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                const f16x8 bh = fr[((t * MB + b) * 2 + 0) * 64 + lane];
-                const f16x8 bl = fr[((t * MB + b) * 2 + 1) * 64 + lane];
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < kt_end) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) lds[(buf ^ 1) * FR_F4 + v * 256 + threadIdx.x] = xs[v];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
+            for (int v = 0; v < NV; ++v) lds[v * 256 + threadIdx.x] = gfr[(size_t)kt0 * FR_F4 + v * 256 + threadIdx.x];
         }
         __syncthreads();
+        for (int li = lb; li < le; ++li) {
+            const int buf = (li - lb) & 1;
+            if (li + 1 < le) {
+                const int ktn = tile_at(li + 1);
+                load_a(ktn, a_nxt);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) xs[v] = gfr[(size_t)ktn * FR_F4 + v * 256 + threadIdx.x];
+            }
+            const f16x8 *fr = reinterpret_cast<const f16x8 *>(lds + buf * FR_F4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f16x8 ah, al;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 y = {a_cur[8 * t + e] * ascale, a_cur[8 * t + e + 1] * ascale};
+                    const f16x2 h2 = __builtin_convertvector(y, f16x2);
+                    const f32x2 res = y - __builtin_convertvector(h2, f32x2);
+                    const f16x2 l2 = __builtin_convertvector(res, f16x2);
+                    ah[e] = h2[0];
+                    ah[e + 1] = h2[1];
+                    al[e] = l2[0];
+                    al[e + 1] = l2[1];
+                }
+#pragma unroll
+                for (int b = 0; b < MB; ++b) {
+                    const f16x8 bh = fr[((t * MB + b) * 2 + 0) * 64 + lane];
+                    const f16x8 bl = fr[((t * MB + b) * 2 + 1) * 64 + lane];
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                }
+            }
+            if (li + 1 < le) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) lds[(buf ^ 1) * FR_F4 + v * 256 + threadIdx.x] = xs[v];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
+            }
+            __syncthreads();
+        }
+    };
+    if (radius < 0) {
+        // dense: blockIdx.y sweeps tiles [ntiles y / Y, ntiles (y+1) / Y); with gridDim.y > 1 the partial
+        // sums go to slab blockIdx.y of Ypart and k_mv_sum_splits adds the slabs in order
+        sweep((int)((int64_t)ntiles * blockIdx.y / gridDim.y), (int)((int64_t)ntiles * (blockIdx.y + 1) / gridDim.y));
+    } else {
+        // skipping: one workgroup walks the slabs of the dense run one after the other and adds the
+        // slab sums in the same order -- the skipped tiles contribute exact zeros, so Y is bit-identical
+        f32x16 run[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) run[b][r] = 0.f;
+        int lpos = 0;
+        for (int sl = 0; sl < nslabs; ++sl) {
+            const int t_end = (int)((int64_t)ntiles * (sl + 1) / nslabs);
+            int le = lpos;
+            while (le < nlist && tlist[le] < t_end) ++le;
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            sweep(lpos, le);
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) run[b][r] += acc[b][r];
+            lpos = le;
+        }
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[b] = run[b];
     }
     float *dst = gridDim.y > 1 ? Ypart + (size_t)blockIdx.y * p_pad * LD : Y;
 #pragma unroll
@@ -284,6 +357,8 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
     const unsigned row0 = sharded ? shard->row0 : 0u, row1 = sharded ? shard->row1 : p;
     // element (k, row) of the symmetric operator sits at A[k * lda + (row - row0)]
     const float *A_eff = A - row0;
+    const int4 *kbox = shard ? shard->kbox : nullptr;
+    const int radius = (kbox && shard->radius >= 0 && p_pad / 64 <= (unsigned)MV_MAXTILES) ? shard->radius : -1;
     hipStream_t st = ctx->stream;
     // scratch lives in the context (reused by every mat-vec of a solve; no allocation in the loop)
     // K split so that the grid fills the 2-workgroups-per-CU residency evenly (the kernel keeps
@@ -318,15 +393,17 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
     hipLaunchKernelGGL(k_mv_x_split, dim3((unsigned)ceil_div((int64_t)p_pad * ld, 256)), dim3(256), 0, st, X, p_pad, ld, scales,
                        xfrag);
     if (row1 > row0) {
-        dim3 grid((unsigned)nrb, (unsigned)ksplit), block(256);
+        // with tile skipping one workgroup per row block replays the dense run's slabs itself (bit-identical Y)
+        const bool skipping = radius >= 0;
+        dim3 grid((unsigned)nrb, skipping ? 1u : (unsigned)ksplit), block(256);
         switch (ld / 32) {
-        case 1: hipLaunchKernelGGL(k_block_matvec_f16s<1>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
-        case 2: hipLaunchKernelGGL(k_block_matvec_f16s<2>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
-        case 4: hipLaunchKernelGGL(k_block_matvec_f16s<4>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
-        case 8: hipLaunchKernelGGL(k_block_matvec_f16s<8>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart); break;
+        case 1: hipLaunchKernelGGL(k_block_matvec_f16s<1>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
+        case 2: hipLaunchKernelGGL(k_block_matvec_f16s<2>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
+        case 4: hipLaunchKernelGGL(k_block_matvec_f16s<4>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
+        case 8: hipLaunchKernelGGL(k_block_matvec_f16s<8>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
         default: return set_error(ctx, GLF_ERR_UNSUPPORTED, "ld %u", ld);
         }
-        if (ksplit > 1)
+        if (ksplit > 1 && !skipping)
             hipLaunchKernelGGL(k_mv_sum_splits, dim3((unsigned)ceil_div((int64_t)(row1 - row0) * ld, 256)), dim3(256), 0, st, ypart,
                                ksplit, p_pad, row0, row1, ld, scales, Y);
     }

@@ -156,6 +156,11 @@ int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, 
 // all-gather block (a multiple of 64 >= ceil(p / size)); 0 = not sharded (A is the full matrix).
 struct MatShard {
     unsigned row0 = 0, row1 = 0, rows_per_rank = 0;
+    // Exact-zero tile skipping of the split-f16 mat-vec (optional): kbox[c] = bounding box {rmin, rmax,
+    // cmin, cmax} of samples [64 c, 64 c + 64); a (128-row block, 64-k tile) pair whose boxes are more
+    // than `radius` pixels apart holds only entries with |2^10 A| < 2^-25, i.e. f16 hi = lo = 0.
+    const int4 *kbox = nullptr;
+    int radius = -1;
 };
 inline unsigned shard_rows_per_rank(unsigned p, int size) { return (unsigned)round_up(ceil_div(p, size), VEC_PAD); }
 // rows to allocate for a p x ld vector block (zero padded) so that the all-gather blocks fit
@@ -187,6 +192,8 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
                       KernelCoef coef, float scale, const float *d_psi, unsigned m, unsigned ld,
                       float *d_phi, int raster, double *d_c, float *kernel_ms, int window = 0,
                       uint64_t *chunks_visited = nullptr);
+// box[c] = {rmin, rmax, cmin, cmax} of samples [64 c, 64 c + 64) (nystroem.hip)
+int chunk_boxes(glf_ctx *ctx, const float4 *d_samples, unsigned p, int4 *d_box);
 // Phi rows of the sample pixels <- Phi_A rows (hpc/nystroem.c:25-34 + hpc/utils.c:149-152)
 int scatter_sample_rows(glf_ctx *ctx, const float *d_phiA, unsigned p, unsigned ld, const uint32_t *d_idx,
                         float *d_phi, int raster, const uint8_t *d_img, double *d_c, unsigned m);

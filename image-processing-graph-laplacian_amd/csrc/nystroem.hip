@@ -261,6 +261,14 @@ static int sum_rows(glf_ctx *ctx, const double *d_in, int64_t nrows, unsigned ld
     return GLF_OK;
 }
 
+int chunk_boxes(glf_ctx *ctx, const float4 *d_samples, unsigned p, int4 *d_box)
+{
+    const unsigned nchunks = (unsigned)ceil_div(p, 64);
+    hipLaunchKernelGGL(k_chunk_boxes, dim3((nchunks + 63) / 64), dim3(64), 0, ctx->stream, d_samples, p, d_box);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
 // Host side of the exact-zero skipping: radius from the contraction's arithmetic, chunk boxes, and
 // the per-workgroup "chunks visited" counters (summed for the executed-work accounting).
 struct NysWindow {

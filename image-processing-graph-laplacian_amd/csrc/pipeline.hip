@@ -336,6 +336,15 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
         shard.row0 = (unsigned)(b < p ? b : p);
         shard.row1 = (unsigned)(b + shard.rows_per_rank < p ? b + shard.rows_per_rank : p);
     }
+    // Exact-zero tile skipping of the mat-vec: |2^10 L_A[i][j]| = 2^10 alpha K < 2^-25 once t > 35 + log2(alpha)
+    DevBuf<int4> kbox;
+    if (opt.skip_exact_zeros && coef.s_loc > 0.f && ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
+        const double t_zero = 35.5 + std::log2(alpha);
+        GLF_TRY(kbox.alloc(ctx, (size_t)ceil_div(p, 64)));
+        GLF_TRY(chunk_boxes(ctx, tb.samples.p, p, kbox.p));
+        shard.kbox = kbox.p;
+        shard.radius = t_zero > 0.0 ? (int)std::floor(std::sqrt(t_zero / (double)coef.s_loc)) + 1 : 0;
+    }
     const unsigned la_cols = shard_eig ? shard.row1 - shard.row0 : p;
     const int64_t lda = shard_eig ? round_up(la_cols ? la_cols : 1, VEC_PAD) : (int64_t)p32;
     DevBuf<float> LA, dinv;
@@ -356,7 +365,7 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
         glf_random_vectors(X0.data(), p, m, opt.seed);
         int rc = inverse_power_iteration(ctx, LA.p, lda, p, m, ld, X0.data(), opt.opti_gs, opt.epsilon, opt.inner_rtol,
                                          opt.max_outer > 0 ? opt.max_outer : 100000, phiA.p, lam.data(), &S.eig,
-                                         shard_eig ? &shard : nullptr, dinv.p);
+                                         (shard_eig || shard.kbox) ? &shard : nullptr, dinv.p);
         if (rc != GLF_OK) return rc;
     }
     LA.release();
