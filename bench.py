@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 import glf  # noqa: E402  (HIP path; raises if libglf.so is missing)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)" dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -42,6 +43,8 @@ def parse_args():
     ap.add_argument("--num-eigvals", type=int, default=64)
     ap.add_argument("--epsilon", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-skip-leg", action="store_true",
+                    help="do not time the extra exact-zero-skipping leg (reported beside the headline)")
     ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args()
 
@@ -150,26 +153,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    info = None
-    for _ in range(args.warmup):
-        _, _, info = ctx.image_processing(d_img, opt, out=d_out)
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
-    for _ in range(args.steps):
-        _, _, info = ctx.image_processing(d_img, opt, out=d_out)
-        kernel_ms.append(info["nystroem_kernel_ms"])
-        for k in stage_ms:
-            stage_ms[k] += info[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = N / (elapsed / args.steps) * 1e-6
+    def run_leg(opt):
+        """W untimed + K timed whole-path steps; returns (seconds per step over all ranks, last info,
+        mean Nystroem kernel ms, mean stage ms)."""
+        info = None
+        for _ in range(args.warmup):
+            _, _, info = ctx.image_processing(d_img, opt, out=d_out)
+        barrier()
+        t0 = time.perf_counter()
+        kernel_ms = []
+        stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
+        for _ in range(args.steps):
+            _, _, info = ctx.image_processing(d_img, opt, out=d_out)
+            kernel_ms.append(info["nystroem_kernel_ms"])
+            for k in stage_ms:
+                stage_ms[k] += info[k]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed / args.steps, info, float(np.mean(kernel_ms)), {k[3:]: round(v / args.steps, 3) for k, v in stage_ms.items()}
+
+    sec_per_step, info, avg_ms, stage_ms = run_leg(opt)
+    ms_per_step = sec_per_step * 1e3
+    value = N / sec_per_step * 1e-6
+    skip_leg = None
+    if not args.no_skip_leg:
+        opt_skip = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals,
+                                       epsilon=args.epsilon, skip_exact_zeros=1)
+        skip_leg = run_leg(opt_skip)
 
     if rank == 0:
         p, m = info["p"], info["m"]
@@ -179,24 +193,58 @@ def main():
         # algorithmic flops of ONE launch of the Nystroem contraction on this rank:
         # 2 * (non-sample pixels) * p * m   (W_nys = 2 (N - p) p m)
         flops = 2.0 * (npix_local - n_samples_local) * p * m
-        avg_ms = float(np.mean(kernel_ms))
         achieved = flops / (avg_ms * 1e-3) / 1e12
+        ld = 32
+        while ld < m:
+            ld *= 2
+        if info["contraction"] == glf.CONTRACT_F16_SPLIT:
+            # every f32-equivalent multiply-add is three f16 MFMA products (hi*hi + hi*lo + lo*hi)
+            peak = PEAK_F16_MFMA_TFLOPS / 3.0
+            issued = 3.0 * 2.0 * info["nystroem_evaluated"] * ld / (avg_ms * 1e-3) / 1e12
+            kernel = ("k_nystroem_f16s<%d,%d> (Nystroem contraction; K_B generated in registers, both operands split into "
+                      "f16 hi+lo pairs, v_mfma_f32_32x32x16_f16, f32 accumulate)" % (ld // 32, 2 if ld <= 64 else 1))
+            basis = "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add"
+        else:
+            peak, issued = PEAK_F32_MFMA_TFLOPS, achieved
+            kernel = "k_nystroem<%d,%d> (Nystroem contraction, v_mfma_f32_32x32x2_f32, K_B generated in registers)" % (ld // 32, 2 if ld <= 128 else 1)
+            basis = "f32 dense matrix peak"
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this configuration
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "%dx%d_m%d_%s_gpus%d" % (size, size, m, "f16s" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32", n_gpus)
+            traffic = prof.get(key, {}).get("nystroem_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "filtered Mpixels/sec @ 4K img, 0.5% samples",
             "value": round(value, 4), "unit": "Mpixel/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g, "
-                                   "dense K_B (no spatial truncation)" % (size, size, args.sample_frac * 100, p, m, args.epsilon),
+                                   "every K_B entry evaluated (no skipping)" % (size, size, args.sample_frac * 100, p, m, args.epsilon),
                        "N": N, "p": p, "m": m, "epsilon": args.epsilon, "outer_its": info["outer_its"],
                        "inner_its_total": info["inner_its_total"], "residual": round(info["residual"], 5),
-                       "sharding": "pixel rows / %d ranks" % n_gpus},
-            "stage_ms_rank0": {k[3:]: round(v / args.steps, 3) for k, v in stage_ms.items()},
-            "roofline": {"kernel": "k_nystroem (Nystroem contraction, f32 MFMA 32x32x2, K_B generated in registers)",
-                         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "avg_launch_ms": round(avg_ms, 3), "flops_per_launch": flops},
+                       "contraction": "f16 split (hi+lo), f32 accumulate" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32 MFMA",
+                       "sharding": "pixel rows / %d ranks; L_A column blocks / %d ranks" % (n_gpus, n_gpus)},
+            "stage_ms_rank0": stage_ms,
+            "roofline": {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1),
+                         "peak_basis": basis, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "avg_launch_ms": round(avg_ms, 3), "flops_per_launch": flops,
+                         "mfma_issued_tflops": round(issued, 1),
+                         "note": "achieved = algorithmic 2 (N-p) p m flop / mean HIP-event duration of the launch"},
         }
+        if skip_leg is not None:
+            s_sec, s_info, s_avg_ms, s_stage = skip_leg
+            dense_evals = float(p) * npix_local
+            line["exact_zero_skipping"] = {
+                "what": "same workload with glf_options.skip_exact_zeros = 1: tiles whose kernel entries are exactly 0 in the "
+                        "arithmetic in use are not evaluated; output bit-identical to the headline run (tests/test_gpu_parity.py)",
+                "value": round(N / s_sec * 1e-6, 4), "unit": "Mpixel/s", "ms_per_step": round(s_sec * 1e3, 3),
+                "stage_ms_rank0": s_stage, "nystroem_kernel_ms": round(s_avg_ms, 3),
+                "fraction_evaluated": {"nystroem": round(s_info["nystroem_evaluated"] / dense_evals, 4),
+                                       "degree": round(s_info["degree_evaluated"] / dense_evals, 4)},
+                "outer_its": s_info["outer_its"],
+            }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, info, args)
         if n_gpus == 1 and not args.no_parity:

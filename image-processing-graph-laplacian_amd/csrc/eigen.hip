@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
 {
     constexpr int LD = MB * 32;
     constexpr int FR_F4 = 4 * MB * 2 * 64; // float4 words of one K tile's X fragments
-    constexpr int NV = FR_F4 / 256;
+    constexpr int PIECES = FR_F4 * 16 / 1024;
     __shared__ __attribute__((aligned(16))) float4 lds[2 * FR_F4];
     __shared__ int tlist[MV_MAXTILES];
     __shared__ int tscratch[257];
@@ -228,7 +228,6 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
     }
     auto tile_at = [&](int i) { return radius < 0 ? i : tlist[i]; };
     float a_cur[32], a_nxt[32];
-    float4 xs[NV];
     auto load_a = [&](int kt, float (&dst)[32]) {
         const unsigned k0 = (unsigned)kt * 64 + 32 * half;
         if (kt + 1 < ntiles) {
@@ -249,17 +248,16 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
         if (lb < le) {
             const int kt0 = tile_at(lb);
             load_a(kt0, a_cur);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) lds[v * 256 + threadIdx.x] = gfr[(size_t)kt0 * FR_F4 + v * 256 + threadIdx.x];
+            lds_dma_copy(gfr + (size_t)kt0 * FR_F4, lds, PIECES, wave, lane);
         }
+        lds_dma_drain();
         __syncthreads();
         for (int li = lb; li < le; ++li) {
             const int buf = (li - lb) & 1;
-            if (li + 1 < le) {
+            if (li + 1 < le) { // next A tile into registers, next X fragments straight into the other LDS buffer
                 const int ktn = tile_at(li + 1);
                 load_a(ktn, a_nxt);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) xs[v] = gfr[(size_t)ktn * FR_F4 + v * 256 + threadIdx.x];
+                lds_dma_copy(gfr + (size_t)ktn * FR_F4, lds + (buf ^ 1) * FR_F4, PIECES, wave, lane);
             }
             const f16x8 *fr = reinterpret_cast<const f16x8 *>(lds + buf * FR_F4);
 #pragma unroll
@@ -287,10 +285,9 @@ __global__ __launch_bounds__(256) void k_block_matvec_f16s(const float *__restri
             }
             if (li + 1 < le) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) lds[(buf ^ 1) * FR_F4 + v * 256 + threadIdx.x] = xs[v];
-#pragma unroll
                 for (int i = 0; i < 32; ++i) a_cur[i] = a_nxt[i];
             }
+            lds_dma_drain();
             __syncthreads();
         }
     };

@@ -120,6 +120,36 @@ __device__ __forceinline__ float kernel_eval(float dr, float dc, float dv, float
     return __builtin_amdgcn_exp2f(-t);
 }
 
+// ---- LDS-DMA staging ---------------------------------------------------------------------------
+// global_load_lds_dwordx4: 64 lanes x 16 B land at LDS byte offset (wave-uniform base) + lane * 16, no
+// VGPRs. Issued from inline asm on purpose: with the builtin, hipcc (ROCm 7.2) cannot prove that the DMA
+// into one staging buffer does not alias the ds_reads of the other and puts s_waitcnt vmcnt(0) in front
+// of the MFMA loop; staged through a register array instead, the array became a stack object (scratch:
+// tens of GB of HBM writes per launch). The issuing wave must call lds_dma_drain() before the barrier that
+// hands the buffer to its readers.
+__device__ __forceinline__ void lds_dma_16B(const void *gptr, unsigned lds_byte_offset)
+{
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(gptr), "s"(lds_byte_offset)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_offset_of(const void *lds_ptr)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)(const char *)lds_ptr;
+}
+// copy `pieces` KiB-sized pieces global -> LDS, piece i handled by wave (i % 4) of a 256-thread workgroup
+__device__ __forceinline__ void lds_dma_copy(const void *gsrc, void *ldst, int pieces, int wave, int lane)
+{
+    const char *g = reinterpret_cast<const char *>(gsrc);
+    const unsigned base = lds_offset_of(ldst);
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    for (int i = uw; i < pieces; i += 4) lds_dma_16B(g + (size_t)i * 1024 + lane * 16, base + (unsigned)i * 1024u);
+}
+
 // ---- stage implementations (device pointers, all on ctx->stream) -----------------
 
 // Sample table: float4 {row, col, value, 0} per sample + mask + device idx.

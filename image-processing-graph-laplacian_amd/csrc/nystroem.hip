@@ -93,7 +93,7 @@ __device__ __forceinline__ int build_chunk_list(const int4 *__restrict__ box, in
     return scratch[256];
 }
 
-template <int MB, int PB> // MB = ld / 32 column blocks; PB = 32-pixel blocks per wave
+template <int MB, int PB, bool SKIP> // MB = ld / 32 column blocks; PB = 32-pixel blocks per wave; SKIP: chunk list
 __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ img, int width, int64_t pix0, int64_t pix1,
                                                    const float4 *__restrict__ samples, unsigned p, float s_loc,
                                                    float s_val, const float *__restrict__ psi,
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ im
 {
     constexpr int LD = MB * 32;
     constexpr int KC = NYS_KC;
-    __shared__ int clist[NYS_MAXCH];
-    __shared__ int cscratch[257];
+    __shared__ int clist[SKIP ? NYS_MAXCH : 1];
+    __shared__ int cscratch[SKIP ? 257 : 1];
     // one array for everything (guide: a second __shared__ object can de-pipeline LDS staging)
     __shared__ __attribute__((aligned(16))) float lds[2 * (NYS_KC * 4 + NYS_KC * MB * 32)];
     constexpr int BUF = KC * 4 + KC * LD; // floats per buffer: sample table then Psi tile
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ im
     const int nchunks = (int)((p + KC - 1) / KC);
     const int64_t wg_first = pix0 + (int64_t)blockIdx.x * (128 * PB);
     const int64_t wg_last = min(wg_first + 128 * PB, pix1) - 1;
-    const int nlist = build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch);
+    const int nlist = SKIP ? build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch) : nchunks;
     if (visited && threadIdx.x == 0) visited[blockIdx.x] = (unsigned)nlist;
-    auto chunk_at = [&](int i) { return radius < 0 ? i : clist[i]; };
+    auto chunk_at = [&](int i) { return SKIP ? clist[i] : i; };
     auto stage = [&](int chunk, int buf) {
         const unsigned s0 = (unsigned)chunk * KC;
         if (threadIdx.x < KC) {
@@ -315,9 +315,14 @@ static int launch_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int64_
     NysWindow win;
     GLF_TRY(win.init(ctx, d_samples, p, coef, window, 151.0, nwg));
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-    hipLaunchKernelGGL((k_nystroem<MB, PB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, d_img, width, pix0, pix1,
-                       d_samples, p, coef.s_loc, coef.s_val, d_psi, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
-                       win.box.p, win.radius, win.visited.p);
+    if (win.radius >= 0)
+        hipLaunchKernelGGL((k_nystroem<MB, PB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, d_img, width, pix0, pix1,
+                           d_samples, p, coef.s_loc, coef.s_val, d_psi, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
+                           win.box.p, win.radius, win.visited.p);
+    else
+        hipLaunchKernelGGL((k_nystroem<MB, PB, false>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, d_img, width, pix0, pix1,
+                           d_samples, p, coef.s_loc, coef.s_val, d_psi, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
+                           win.box.p, win.radius, win.visited.p);
     GLF_LAUNCH_CHECK(ctx);
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     if (chunks_visited) GLF_TRY(win.total(ctx, nwg, chunks_visited));
@@ -393,7 +398,7 @@ __global__ void k_col_absmax(const float *__restrict__ psi, unsigned p, unsigned
     if (threadIdx.x == 0) out[c] = sh[0];
 }
 
-template <int MB, int PB>
+template <int MB, int PB, bool SKIP>
 __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict__ img, int width, int64_t pix0, int64_t pix1,
                                                         const float *__restrict__ soa, unsigned p, float s_loc, float s_val,
                                                         const _Float16 *__restrict__ psi16, const float *__restrict__ invscale,
@@ -403,10 +408,9 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                                                         int radius, unsigned *__restrict__ visited)
 {
     constexpr int LD = MB * 32;
-    __shared__ int clist[NYS_MAXCH];
-    __shared__ int cscratch[257];
+    __shared__ int clist[SKIP ? NYS_MAXCH : 1];
+    __shared__ int cscratch[SKIP ? 257 : 1];
     constexpr int PSI_F4 = 4 * MB * 2 * 64;      // float4 (16 B) words of one chunk's Psi fragments
-    constexpr int NV = PSI_F4 / 256;             // per thread
     constexpr int BUF_F4 = 64 + PSI_F4;          // + 1 KiB sample SoA
     __shared__ __attribute__((aligned(16))) float4 lds[2 * BUF_F4];
 
@@ -434,31 +438,25 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
     const int nchunks = (int)((p + 63) / 64);
     const int64_t wg_first = pix0 + (int64_t)blockIdx.x * (128 * PB);
     const int64_t wg_last = min(wg_first + 128 * PB, pix1) - 1;
-    const int nlist = build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch);
+    const int nlist = SKIP ? build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch) : nchunks;
     if (visited && threadIdx.x == 0) visited[blockIdx.x] = (unsigned)nlist;
-    auto chunk_at = [&](int i) { return radius < 0 ? i : clist[i]; };
+    auto chunk_at = [&](int i) { return SKIP ? clist[i] : i; };
     const float4 *gsoa = reinterpret_cast<const float4 *>(soa);
     const float4 *gpsi = reinterpret_cast<const float4 *>(psi16);
-    float4 stage_s, stage_p[NV];
-    auto g_load = [&](int chunk) {
-        if (threadIdx.x < 64) stage_s = gsoa[(size_t)chunk * 64 + threadIdx.x];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) stage_p[v] = gpsi[(size_t)chunk * PSI_F4 + v * 256 + threadIdx.x];
-    };
-    auto l_store = [&](int buf) {
+    // Double-buffered LDS-DMA staging: a chunk is 1 KiB of sample SoA + PSI_F4 * 16 B of Psi fragments,
+    // contiguous in both tables, copied with no VGPRs while the previous chunk is being contracted.
+    constexpr int PIECES = PSI_F4 * 16 / 1024;
+    auto stage = [&](int chunk, int buf) {
         float4 *dst = lds + buf * BUF_F4;
-        if (threadIdx.x < 64) dst[threadIdx.x] = stage_s;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) dst[64 + v * 256 + threadIdx.x] = stage_p[v];
+        if (wave == 0) lds_dma_16B(reinterpret_cast<const char *>(gsoa + (size_t)chunk * 64) + lane * 16, lds_offset_of(dst));
+        lds_dma_copy(gpsi + (size_t)chunk * PSI_F4, dst + 64, PIECES, wave, lane);
     };
-    if (nlist > 0) {
-        g_load(chunk_at(0));
-        l_store(0);
-    }
+    if (nlist > 0) stage(chunk_at(0), 0);
+    lds_dma_drain();
     __syncthreads();
     for (int ch = 0; ch < nlist; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nlist) g_load(chunk_at(ch + 1)); // in flight during the MFMA/VALU sweep below
+        if (ch + 1 < nlist) stage(chunk_at(ch + 1), buf ^ 1); // in flight during the MFMA/VALU sweep below
         const float *ssoa = reinterpret_cast<const float *>(lds + buf * BUF_F4);
         const f16x8 *sfrag = reinterpret_cast<const f16x8 *>(lds + buf * BUF_F4 + 64);
 #pragma unroll
@@ -505,8 +503,8 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                 }
             }
         }
-        if (ch + 1 < nlist) l_store(buf ^ 1);
-        __syncthreads();
+        lds_dma_drain(); // this wave's pieces of the next chunk have landed ...
+        __syncthreads(); // ... and so have everybody else's; buffer `buf` is free again
     }
 
     // ---- epilogue (same as k_nystroem, plus the exact power-of-two rescale per column)
@@ -603,9 +601,14 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     NysWindow win;
     GLF_TRY(win.init(ctx, d_samples, p, coef, window, 40.5, nwg));
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[6], st));
-    hipLaunchKernelGGL((k_nystroem_f16s<MB, PB>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
-                       coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
-                       win.box.p, win.radius, win.visited.p);
+    if (win.radius >= 0)
+        hipLaunchKernelGGL((k_nystroem_f16s<MB, PB, true>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
+                           coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
+                           win.box.p, win.radius, win.visited.p);
+    else
+        hipLaunchKernelGGL((k_nystroem_f16s<MB, PB, false>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
+                           coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
+                           win.box.p, win.radius, win.visited.p);
     GLF_LAUNCH_CHECK(ctx);
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], st));
     if (chunks_visited) GLF_TRY(win.total(ctx, nwg, chunks_visited));

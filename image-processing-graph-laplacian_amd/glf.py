@@ -289,7 +289,7 @@ class Context:
                 full = device_tensor_from_ptr(ptr, count_per_rank * size, torch.float32, dev)
                 mine = full[rank * count_per_rank:(rank + 1) * count_per_rank]
                 if on_device:
-                    dist.all_gather_into_tensor(full, mine, group=group)   # in place (RCCL allows it)
+                    dist.all_gather_into_tensor(full, mine.clone(), group=group)
                 else:
                     parts = [torch.empty(count_per_rank, dtype=torch.float32) for _ in range(size)]
                     dist.all_gather(parts, mine.cpu(), group=group)
