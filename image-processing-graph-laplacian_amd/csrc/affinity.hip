@@ -52,79 +52,82 @@ int build_sample_tables(glf_ctx *ctx, const uint8_t *d_img, int width, int heigh
 
 // ---- degree: D[i] = sum_pixels K(sample i, pixel) --------------------------------------
 //
-// lane = sample (its row/col/value live in VGPRs), loop over pixels whose values
-// are staged per image row in LDS as floats and read back as wave-wide
-// broadcasts (ds_read_b128 = 4 pixels). VALU/transcendental-bound by design:
-// HBM traffic is ~N bytes per sample block. 7 VALU + 1 v_exp_f32 per entry.
-// Accumulation: f32 within one image row, f64 across rows and chunks
-// (fixed order => bitwise reproducible).
+// lane = sample (its row/col/value live in VGPRs); a workgroup (256 samples) sweeps a chunk of 16
+// image rows. The Gaussian is separable in the two coordinates, so per pixel only the photometric
+// part needs an exponential:
+//     K = exp2(-(a_r + s_val dv^2)) * Ec,   a_r = s_loc (r_i - r)^2  (16 registers per chunk),
+//                                           Ec  = exp2(-s_loc (c_i - c)^2)  (once per column, 16 rows)
+// = 4 VALU + 1 v_exp_f32 per entry (7 + 1 without the factorisation). Pixel values are staged as
+// floats in a 16-row LDS tile and read back as wave-wide broadcasts (ds_read_b128 = 4 pixels).
+// VALU/transcendental-bound by design: HBM traffic is ~N bytes per sample block.
+// Accumulation: f32 over one 4-column x 16-row strip (64 terms), f64 across strips, chunks and the
+// final reduction, all in a fixed order => bitwise reproducible, and identical between the dense sweep
+// and the exact-zero-skipping sweep (which visits a 4-column / 16-row aligned sub-range).
 
 constexpr int DEG_THREADS = 256;
-constexpr int DEG_MAXW = 8192; // floats of LDS per staged row segment
+constexpr int DEG_ROWS = 16;   // rows per chunk (fixed: part of the accumulation order)
+constexpr int DEG_SEGW = 512;  // columns per staged LDS tile
 
-__global__ __launch_bounds__(DEG_THREADS) void k_degree(const uint8_t *__restrict__ img, int width, int row0,
-                                                         int row1, int rows_per_chunk,
-                                                         const float4 *__restrict__ samples, unsigned p,
-                                                         float s_loc, float s_val, double *__restrict__ partial)
+// Sum over rows [r_begin, r_end) (at most DEG_ROWS) and columns [c_begin, c_end), c_begin % 4 == 0.
+__device__ __forceinline__ double degree_chunk(const uint8_t *__restrict__ img, int width, int r_begin, int r_end, int c_begin,
+                                               int c_end, float4 s, float s_loc, float s_val, float *tile /* [16][SEGW] */)
 {
-    __shared__ __attribute__((aligned(16))) float rowv[DEG_MAXW];
-    const unsigned i = blockIdx.x * DEG_THREADS + threadIdx.x;
-    const bool live = i < p;
-    const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int r_begin = row0 + (int)blockIdx.y * rows_per_chunk;
-    const int r_end = min(r_begin + rows_per_chunk, row1);
+    const int nr = r_end - r_begin;
+    float a[DEG_ROWS];
+#pragma unroll
+    for (int r = 0; r < DEG_ROWS; ++r) {
+        const float dr = s.x - (float)(r_begin + r);
+        a[r] = dr * dr * s_loc;
+    }
     double total = 0.0;
-    for (int r = r_begin; r < r_end; ++r) {
-        const float dr = s.x - (float)r;
-        const float a = dr * dr * s_loc;
-        for (int c0 = 0; c0 < width; c0 += DEG_MAXW) {
-            const int seg = min(DEG_MAXW, width - c0);
-            const int seg4 = (seg + 3) & ~3;
-            __syncthreads(); // previous segment fully consumed
-            for (int c = threadIdx.x; c < seg4; c += DEG_THREADS)
-                // pad with a value that makes the kernel entry exactly 0 only through the
-                // guard below; padded lanes are skipped, the value is irrelevant
-                rowv[c] = (c < seg) ? (float)img[(size_t)r * width + c0 + c] : 0.f;
-            __syncthreads();
-            float acc = 0.f;
-            float dc = s.y - (float)c0; // exact integer, decremented per pixel
-            const int full4 = seg & ~3;
-            for (int c = 0; c < full4; c += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(&rowv[c]);
-                {
-                    const float dv = s.z - v.x;
-                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                    acc += __builtin_amdgcn_exp2f(-t);
-                    dc -= 1.f;
-                }
-                {
-                    const float dv = s.z - v.y;
-                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                    acc += __builtin_amdgcn_exp2f(-t);
-                    dc -= 1.f;
-                }
-                {
-                    const float dv = s.z - v.z;
-                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                    acc += __builtin_amdgcn_exp2f(-t);
-                    dc -= 1.f;
-                }
-                {
-                    const float dv = s.z - v.w;
-                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                    acc += __builtin_amdgcn_exp2f(-t);
-                    dc -= 1.f;
-                }
-            }
-            for (int c = full4; c < seg; ++c) {
-                const float dv = s.z - rowv[c];
-                const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                acc += __builtin_amdgcn_exp2f(-t);
+    for (int c0 = c_begin; c0 < c_end; c0 += DEG_SEGW) {
+        const int seg = min(DEG_SEGW, c_end - c0);
+        const int seg4 = (seg + 3) & ~3;
+        __syncthreads(); // previous tile fully consumed
+        for (int e = threadIdx.x; e < nr * seg4; e += DEG_THREADS) {
+            const int r = e / seg4, c = e % seg4;
+            tile[r * DEG_SEGW + c] = (c < seg) ? (float)img[(size_t)(r_begin + r) * width + c0 + c] : 0.f;
+        }
+        __syncthreads();
+        float dc = s.y - (float)c0; // exact integer, decremented per column
+        for (int c = 0; c < seg4; c += 4) {
+            float ec[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // columns past the end of the range (padding of the last strip) get weight 0
+                ec[u] = (c + u < seg) ? __builtin_amdgcn_exp2f(-(dc * dc * s_loc)) : 0.f;
                 dc -= 1.f;
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < DEG_ROWS; ++r) {
+                if (r < nr) { // uniform
+                    const float4 v = *reinterpret_cast<const float4 *>(&tile[r * DEG_SEGW + c]);
+                    const float pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float dv = s.z - pv[u];
+                        acc = fmaf(ec[u], __builtin_amdgcn_exp2f(-fmaf(dv * dv, s_val, a[r])), acc);
+                    }
+                }
             }
             total += (double)acc;
         }
     }
+    return total;
+}
+
+__global__ __launch_bounds__(DEG_THREADS) void k_degree(const uint8_t *__restrict__ img, int width, int row0,
+                                                         int row1, const float4 *__restrict__ samples, unsigned p,
+                                                         float s_loc, float s_val, double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float tile[DEG_ROWS * DEG_SEGW];
+    const unsigned i = blockIdx.x * DEG_THREADS + threadIdx.x;
+    const bool live = i < p;
+    const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r_begin = row0 + (int)blockIdx.y * DEG_ROWS;
+    const int r_end = min(r_begin + DEG_ROWS, row1);
+    const double total = degree_chunk(img, width, r_begin, r_end, 0, width, s, s_loc, s_val, tile);
     if (live) partial[(size_t)blockIdx.y * p + i] = total;
 }
 
@@ -147,20 +150,12 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
         return GLF_OK;
     }
     const int nsb = (int)ceil_div(p, DEG_THREADS);
-    const int rows = row1 - row0;
-    // enough workgroups to fill 256 CUs several times over, at most 16 rows per chunk
-    int rows_per_chunk = (int)((int64_t)rows * nsb / 4096);
-    if (rows_per_chunk < 1) rows_per_chunk = 1;
-    if (rows_per_chunk > 16) rows_per_chunk = 16;
-    int nchunks = (int)ceil_div(rows, rows_per_chunk);
-    if (nchunks > 65535) {
-        rows_per_chunk = (int)ceil_div(rows, 65535);
-        nchunks = (int)ceil_div(rows, rows_per_chunk);
-    }
+    const int nchunks = (int)ceil_div(row1 - row0, DEG_ROWS);
+    if (nchunks > 65535) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too tall for one degree launch");
     DevBuf<double> partial;
     GLF_TRY(partial.alloc(ctx, (size_t)nchunks * p));
     hipLaunchKernelGGL(k_degree, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, ctx->stream, d_img, width, row0, row1,
-                       rows_per_chunk, d_samples, p, coef.s_loc, coef.s_val, partial.p);
+                       d_samples, p, coef.s_loc, coef.s_val, partial.p);
     GLF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks,
                        d_degree);
@@ -175,54 +170,24 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
 // rest would add +0 (or denormals that cannot change a sum >= 1). Samples are taken in a tile-major
 // order (perm) so that a block is compact in both directions. Same accumulation structure as k_degree.
 __global__ __launch_bounds__(DEG_THREADS) void k_degree_win(const uint8_t *__restrict__ img, int width, int row0, int row1,
-                                                             int rows_per_chunk, const float4 *__restrict__ samples,
-                                                             unsigned p, const uint32_t *__restrict__ perm,
+                                                             const float4 *__restrict__ samples, unsigned p,
+                                                             const uint32_t *__restrict__ perm,
                                                              const int4 *__restrict__ blk_box, int radius, float s_loc,
                                                              float s_val, double *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) float rowv[DEG_MAXW];
+    __shared__ __attribute__((aligned(16))) float tile[DEG_ROWS * DEG_SEGW];
     const uint32_t i = perm[blockIdx.x * DEG_THREADS + threadIdx.x]; // 0xFFFFFFFF = padding
     const bool live = i < p;
     const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 box = blk_box[blockIdx.x]; // {rmin, rmax, cmin, cmax} of the block's samples
-    const int rw0 = max(row0, box.x - radius), rw1 = min(row1, box.y + radius + 1);
+    // window, snapped to the dense sweep's 16-row chunks and 4-column strips (same accumulation order)
+    const int rw0 = row0 + ((max(row0, box.x - radius) - row0) / DEG_ROWS) * DEG_ROWS;
+    const int rw1 = min(row1, box.y + radius + 1);
     const int cw0 = max(0, box.z - radius) & ~3, cw1 = min(width, box.w + radius + 1);
-    const int r_begin = rw0 + (int)blockIdx.y * rows_per_chunk;
-    const int r_end = min(r_begin + rows_per_chunk, rw1);
+    const int r_begin = rw0 + (int)blockIdx.y * DEG_ROWS;
+    const int r_end = min(r_begin + DEG_ROWS, min(rw1 + DEG_ROWS, row1)); // whole chunk, as the dense sweep
     double total = 0.0;
-    for (int r = r_begin; r < r_end; ++r) { // r_begin >= r_end: nothing to do, partial = 0
-        const float dr = s.x - (float)r;
-        const float a = dr * dr * s_loc;
-        for (int c0 = cw0; c0 < cw1; c0 += DEG_MAXW) {
-            const int seg = min(DEG_MAXW, cw1 - c0);
-            const int seg4 = (seg + 3) & ~3;
-            __syncthreads();
-            for (int c = threadIdx.x; c < seg4; c += DEG_THREADS)
-                rowv[c] = (c < seg) ? (float)img[(size_t)r * width + c0 + c] : 0.f;
-            __syncthreads();
-            float acc = 0.f;
-            float dc = s.y - (float)c0;
-            const int full4 = seg & ~3;
-            for (int c = 0; c < full4; c += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(&rowv[c]);
-                const float pv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float dv = s.z - pv[u];
-                    const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                    acc += __builtin_amdgcn_exp2f(-t);
-                    dc -= 1.f;
-                }
-            }
-            for (int c = full4; c < seg; ++c) {
-                const float dv = s.z - rowv[c];
-                const float t = fmaf(dv * dv, s_val, fmaf(dc * dc, s_loc, a));
-                acc += __builtin_amdgcn_exp2f(-t);
-                dc -= 1.f;
-            }
-            total += (double)acc;
-        }
-    }
+    if (r_begin < rw1) total = degree_chunk(img, width, r_begin, r_end, cw0, cw1, s, s_loc, s_val, tile); // uniform branch
     if (live) partial[(size_t)blockIdx.y * p + i] = total;
 }
 
@@ -260,14 +225,15 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
             rmin = std::min(rmin, r); rmax = std::max(rmax, r); cmin = std::min(cmin, c); cmax = std::max(cmax, c);
         }
         box[b] = make_int4(rmin, rmax, cmin, cmax);
-        const int rows = std::max(0, std::min(row1, rmax + radius + 1) - std::max(row0, rmin - radius));
+        const int rw0 = row0 + ((std::max(row0, rmin - radius) - row0) / DEG_ROWS) * DEG_ROWS;
+        const int rw1 = std::min(row1, rmax + radius + 1);
+        const int rows = std::max(0, std::min(row1, rw0 + (int)ceil_div(std::max(0, rw1 - rw0), DEG_ROWS) * DEG_ROWS) - rw0);
         const int cols = std::min(width, cmax + radius + 1) - (std::max(0, cmin - radius) & ~3);
         max_rows = std::max(max_rows, rows);
         evals += (double)DEG_THREADS * rows * cols;
     }
     if (evaluated) *evaluated = evals;
-    const int rows_per_chunk = 16;
-    const int nchunks = (int)ceil_div(max_rows, rows_per_chunk);
+    const int nchunks = (int)ceil_div(max_rows, DEG_ROWS);
     DevBuf<uint32_t> d_perm;
     DevBuf<int4> d_box;
     DevBuf<double> partial;
@@ -277,7 +243,7 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
     GLF_HIP(ctx, hipMemcpyAsync(d_perm.p, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice, ctx->stream));
     GLF_HIP(ctx, hipMemcpyAsync(d_box.p, box.data(), sizeof(int4) * box.size(), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_degree_win, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, ctx->stream, d_img, width, row0, row1,
-                       rows_per_chunk, d_samples, p, d_perm.p, d_box.p, radius, coef.s_loc, coef.s_val, partial.p);
+                       d_samples, p, d_perm.p, d_box.p, radius, coef.s_loc, coef.s_val, partial.p);
     GLF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks, d_degree);
     GLF_LAUNCH_CHECK(ctx);

@@ -79,6 +79,7 @@ int glf_ctx_destroy(glf_ctx *ctx)
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
+    glf::pool_free_all(ctx, false);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GLF_OK;
@@ -237,6 +238,66 @@ void glf_host_free(void *ptr) { std::free(ptr); }
 } // extern "C"
 
 namespace glf {
+
+void *pool_get(glf_ctx *ctx, size_t bytes)
+{
+    const size_t need = (size_t)round_up((int64_t)bytes, 256);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+        const glf_pool_block &b = ctx->pool[i];
+        if (b.in_use || b.bytes < need || b.bytes > need + need / 2 + (1u << 20)) continue;
+        if (best < 0 || b.bytes < ctx->pool[best].bytes) best = i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].in_use = true;
+        return ctx->pool[best].p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) { // make room: drop every cached block nobody is using, then retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        pool_free_all(ctx, true);
+        e = hipMalloc(&p, need);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error(ctx, GLF_ERR_NOMEM, "hipMalloc(%zu bytes) -> %s", need, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->pool.push_back(glf_pool_block{p, need, true});
+    return p;
+}
+
+void pool_put(glf_ctx *ctx, void *ptr)
+{
+    if (!ctx || !ptr) return;
+    for (auto &b : ctx->pool)
+        if (b.p == ptr) {
+            b.in_use = false;
+            return;
+        }
+    (void)hipFree(ptr); // not ours: plain allocation
+}
+
+void pool_forget(glf_ctx *ctx, void *ptr)
+{
+    for (size_t i = 0; i < ctx->pool.size(); ++i)
+        if (ctx->pool[i].p == ptr) {
+            ctx->pool.erase(ctx->pool.begin() + (long)i);
+            return;
+        }
+}
+
+void pool_free_all(glf_ctx *ctx, bool only_unused)
+{
+    std::vector<glf_pool_block> keep;
+    for (auto &b : ctx->pool) {
+        if (only_unused && b.in_use) keep.push_back(b);
+        else (void)hipFree(b.p);
+    }
+    ctx->pool.swap(keep);
+}
 
 KernelCoef make_coef(int kernel, float h_loc, float h_val)
 {

@@ -12,7 +12,17 @@
 
 #include "../../include/glf.h"
 
+// Workspace pool of a context: device blocks released by DevBuf are kept and handed out again
+// (same stream => ordering is safe). hipMalloc / hipFree of the multi-GB buffers on every call cost
+// sporadic 1.7 s stalls (driver unmap of a 29 GB block) and a device-wide sync per hipFree.
+struct glf_pool_block {
+    void *p;
+    size_t bytes;
+    bool in_use;
+};
+
 struct glf_ctx {
+    std::vector<glf_pool_block> pool;
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -67,11 +77,17 @@ inline int64_t ceil_div(int64_t x, int64_t q) { return (x + q - 1) / q; }
 inline unsigned ld_for(unsigned m) { unsigned ld = 32; while (ld < m) ld <<= 1; return ld; }
 inline bool valid_ld(unsigned ld) { return ld == 32 || ld == 64 || ld == 128 || ld == 256; }
 
-// RAII device buffer tied to a context's stream (freed with hipFree at scope exit).
+void *pool_get(glf_ctx *ctx, size_t bytes);          // nullptr on failure (last_error set)
+void pool_put(glf_ctx *ctx, void *ptr);              // back to the pool
+void pool_forget(glf_ctx *ctx, void *ptr);           // ownership leaves the pool (caller hipFree's it)
+void pool_free_all(glf_ctx *ctx, bool only_unused);
+
+// RAII device buffer from the context's workspace pool (returned to the pool at scope exit).
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    glf_ctx *owner = nullptr;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -80,23 +96,21 @@ struct DevBuf {
     {
         release();
         n = count;
+        owner = ctx;
         if (count == 0) return GLF_OK;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            return set_error(ctx, GLF_ERR_NOMEM, "hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
-        }
-        return GLF_OK;
+        p = static_cast<T *>(pool_get(ctx, count * sizeof(T)));
+        return p ? GLF_OK : GLF_ERR_NOMEM;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) pool_put(owner, p);
         p = nullptr;
         n = 0;
     }
-    T *take()
+    T *take() // the block becomes a plain hipMalloc'd allocation owned by the caller
     {
         T *q = p;
+        if (q) pool_forget(owner, q);
         p = nullptr;
         n = 0;
         return q;
