@@ -69,8 +69,11 @@ constexpr int DEG_ROWS = 16;   // rows per chunk (fixed: part of the accumulatio
 constexpr int DEG_SEGW = 512;  // columns per staged LDS tile
 
 // Sum over rows [r_begin, r_end) (at most DEG_ROWS) and columns [c_begin, c_end), c_begin % 4 == 0.
+// KY: also accumulate sum K * pixel value into *ky (the K y product of the full-matrix mode).
+template <bool KY>
 __device__ __forceinline__ double degree_chunk(const uint8_t *__restrict__ img, int width, int r_begin, int r_end, int c_begin,
-                                               int c_end, float4 s, float s_loc, float s_val, float *tile /* [16][SEGW] */)
+                                               int c_end, float4 s, float s_loc, float s_val, float *tile /* [16][SEGW] */,
+                                               double *ky = nullptr)
 {
     const int nr = r_end - r_begin;
     float a[DEG_ROWS];
@@ -79,7 +82,7 @@ __device__ __forceinline__ double degree_chunk(const uint8_t *__restrict__ img, 
         const float dr = s.x - (float)(r_begin + r);
         a[r] = dr * dr * s_loc;
     }
-    double total = 0.0;
+    double total = 0.0, total_ky = 0.0;
     for (int c0 = c_begin; c0 < c_end; c0 += DEG_SEGW) {
         const int seg = min(DEG_SEGW, c_end - c0);
         const int seg4 = (seg + 3) & ~3;
@@ -98,7 +101,7 @@ __device__ __forceinline__ double degree_chunk(const uint8_t *__restrict__ img, 
                 ec[u] = (c + u < seg) ? __builtin_amdgcn_exp2f(-(dc * dc * s_loc)) : 0.f;
                 dc -= 1.f;
             }
-            float acc = 0.f;
+            float acc = 0.f, acc_ky = 0.f;
 #pragma unroll
             for (int r = 0; r < DEG_ROWS; ++r) {
                 if (r < nr) { // uniform
@@ -107,13 +110,21 @@ __device__ __forceinline__ double degree_chunk(const uint8_t *__restrict__ img, 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float dv = s.z - pv[u];
-                        acc = fmaf(ec[u], __builtin_amdgcn_exp2f(-fmaf(dv * dv, s_val, a[r])), acc);
+                        if (KY) {
+                            const float k = ec[u] * __builtin_amdgcn_exp2f(-fmaf(dv * dv, s_val, a[r]));
+                            acc += k;
+                            acc_ky = fmaf(k, pv[u], acc_ky);
+                        } else {
+                            acc = fmaf(ec[u], __builtin_amdgcn_exp2f(-fmaf(dv * dv, s_val, a[r])), acc);
+                        }
                     }
                 }
             }
             total += (double)acc;
+            if (KY) total_ky += (double)acc_ky;
         }
     }
+    if (KY) *ky = total_ky;
     return total;
 }
 
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(DEG_THREADS) void k_degree(const uint8_t *__restric
     const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int r_begin = row0 + (int)blockIdx.y * DEG_ROWS;
     const int r_end = min(r_begin + DEG_ROWS, row1);
-    const double total = degree_chunk(img, width, r_begin, r_end, 0, width, s, s_loc, s_val, tile);
+    const double total = degree_chunk<false>(img, width, r_begin, r_end, 0, width, s, s_loc, s_val, tile);
     if (live) partial[(size_t)blockIdx.y * p + i] = total;
 }
 
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(DEG_THREADS) void k_degree_win(const uint8_t *__res
     const int r_begin = rw0 + (int)blockIdx.y * DEG_ROWS;
     const int r_end = min(r_begin + DEG_ROWS, min(rw1 + DEG_ROWS, row1)); // whole chunk, as the dense sweep
     double total = 0.0;
-    if (r_begin < rw1) total = degree_chunk(img, width, r_begin, r_end, cw0, cw1, s, s_loc, s_val, tile); // uniform branch
+    if (r_begin < rw1) total = degree_chunk<false>(img, width, r_begin, r_end, cw0, cw1, s, s_loc, s_val, tile); // uniform branch
     if (live) partial[(size_t)blockIdx.y * p + i] = total;
 }
 
@@ -248,6 +259,86 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
     hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks, d_degree);
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream)); // host vectors and DevBufs are released at scope exit
+    return GLF_OK;
+}
+
+// ---- full-matrix mode (-no_approx): z = clamp(y - L y), L = alpha (D - K) over ALL pixels ---------------
+// hpc/image_processing.c:155-181 (EntireComputation): ComputeEntireAffinityMatrix (hpc/affinity.c:264-336),
+// ComputeEntireLaplacianMatrix (hpc/laplacian.c:44-65), ComputeResultFromEntireLaplacian (hpc/display.c:128-149).
+// The N x N matrices are never stored: (L y)_i = alpha (D_i y_i - (K y)_i) needs only the two row sums, which
+// the degree sweep produces with every pixel as a "sample".
+__global__ void k_pixel_table(const uint8_t *__restrict__ img, int width, int64_t N, float4 *__restrict__ table)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) table[i] = make_float4((float)(i / width), (float)(i % width), (float)img[i], 0.f);
+}
+
+__global__ __launch_bounds__(DEG_THREADS) void k_degree_ky(const uint8_t *__restrict__ img, int width, int height,
+                                                            const float4 *__restrict__ table, unsigned n, float s_loc,
+                                                            float s_val, double *__restrict__ part_d,
+                                                            double *__restrict__ part_ky)
+{
+    __shared__ __attribute__((aligned(16))) float tile[DEG_ROWS * DEG_SEGW];
+    const unsigned i = blockIdx.x * DEG_THREADS + threadIdx.x;
+    const bool live = i < n;
+    const float4 s = live ? table[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r_begin = (int)blockIdx.y * DEG_ROWS;
+    const int r_end = min(r_begin + DEG_ROWS, height);
+    double ky = 0.0;
+    const double d = degree_chunk<true>(img, width, r_begin, r_end, 0, width, s, s_loc, s_val, tile, &ky);
+    if (live) {
+        part_d[(size_t)blockIdx.y * n + i] = d;
+        part_ky[(size_t)blockIdx.y * n + i] = ky;
+    }
+}
+
+__global__ void k_entire_result(const uint8_t *__restrict__ img, const double *__restrict__ D, const double *__restrict__ Ky,
+                                int64_t N, double alpha, uint8_t *__restrict__ out, float *__restrict__ zf)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double y = (double)img[i];
+    double z = y - alpha * (D[i] * y - Ky[i]); // MatAXPY(z, -1, Lapl_y), hpc/display.c:136
+    if (zf) zf[i] = (float)z;
+    z = z > 255.0 ? 255.0 : z;                 // AboveXSetY, :139
+    z = z > 0.0 ? z : 0.0;                     // SetNegativesToZero, :141
+    out[i] = (uint8_t)z;                       // (png_byte) cast, hpc/utils.c:525
+}
+
+int entire_computation(glf_ctx *ctx, const uint8_t *d_img, int width, int height, KernelCoef coef, uint8_t *d_out, float *d_zf,
+                       double *alpha_out)
+{
+    const int64_t N = (int64_t)width * height;
+    if (N > (int64_t)1 << 22) return set_error(ctx, GLF_ERR_UNSUPPORTED, "-no_approx is O(N^2): limited to 4 Mpixel images");
+    const unsigned n = (unsigned)N;
+    const int nsb = (int)ceil_div(n, DEG_THREADS), nchunks = (int)ceil_div(height, DEG_ROWS);
+    if (nchunks > 65535) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too tall");
+    DevBuf<float4> table;
+    DevBuf<double> part_d, part_ky, D, Ky;
+    GLF_TRY(table.alloc(ctx, n));
+    GLF_TRY(part_d.alloc(ctx, (size_t)nchunks * n));
+    GLF_TRY(part_ky.alloc(ctx, (size_t)nchunks * n));
+    GLF_TRY(D.alloc(ctx, n));
+    GLF_TRY(Ky.alloc(ctx, n));
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_pixel_table, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, d_img, width, N, table.p);
+    hipLaunchKernelGGL(k_degree_ky, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, st, d_img, width, height, table.p, n, coef.s_loc,
+                       coef.s_val, part_d.p, part_ky.p);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, st, part_d.p, n, nchunks, D.p);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, st, part_ky.p, n, nchunks, Ky.p);
+    GLF_LAUNCH_CHECK(ctx);
+    // alpha = 1 / mean(D), hpc/laplacian.c:57 + hpc/utils.c:378-388
+    std::vector<double> h(n);
+    GLF_HIP(ctx, hipMemcpyAsync(h.data(), D.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    double sum = 0.0;
+    for (unsigned i = 0; i < n; ++i) sum += h[i];
+    const double alpha = 1.0 / (sum / (double)n);
+    if (alpha_out) *alpha_out = alpha;
+    hipLaunchKernelGGL(k_entire_result, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, d_img, D.p, Ky.p, N, alpha, d_out,
+                       d_zf);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_HIP(ctx, hipStreamSynchronize(st));
     return GLF_OK;
 }
 

@@ -185,6 +185,10 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
                          const float4 *d_samples, unsigned p, const unsigned *h_idx, KernelCoef coef,
                          double *d_degree, double *evaluated);
 
+// -no_approx: z = clamp(y - L y) with the full N x N Laplacian, never stored (affinity.hip)
+int entire_computation(glf_ctx *ctx, const uint8_t *d_img, int width, int height, KernelCoef coef, uint8_t *d_out, float *d_zf,
+                       double *alpha_out);
+
 // K_A (scale = 1, diag untouched) or L_A (scale = -alpha, diagonal alpha * D_i).
 // columns [col0, col0 + ncols) only (ncols = 0: all p columns); out is [p][ld] with local column index
 int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef,

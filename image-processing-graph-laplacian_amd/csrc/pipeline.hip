@@ -255,6 +255,14 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
     return GLF_OK;
 }
 
+int glf_EntireComputation(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int kernel, float h_loc, float h_val,
+                          uint8_t *d_out, float *d_zf, double *alpha_out)
+{
+    if (!ctx || !d_img || !d_out || width <= 0 || height <= 0) return GLF_ERR_INVALID;
+    if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
+    return entire_computation(ctx, d_img, width, height, make_coef(kernel, h_loc, h_val), d_out, d_zf, alpha_out);
+}
+
 // ------------------------------------------------------------------------------------------
 // Whole approximate path
 // ------------------------------------------------------------------------------------------

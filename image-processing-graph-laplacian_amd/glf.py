@@ -43,7 +43,7 @@ EXPORTS = [
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
     "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
-    "glf_options_default", "glf_image_processing", "glf_read_png", "glf_write_png",
+    "glf_options_default", "glf_image_processing", "glf_EntireComputation", "glf_read_png", "glf_write_png",
 ]
 
 
@@ -431,6 +431,21 @@ class Context:
             "ComputeResultFromLaplacian")
         self.stream.synchronize()
         return out, zf
+
+    def EntireComputation(self, d_img, kernel=KERNEL_BILATERAL, h_loc=40.0, h_val=30.0):
+        """-no_approx mode (hpc/image_processing.c:155-181): z = clamp(y - L y), full N x N Laplacian."""
+        torch = self.torch
+        h, w = d_img.shape
+        with torch.cuda.stream(self.stream):
+            out = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+            zf = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        alpha = C.c_double()
+        self._check(_lib.glf_EntireComputation(self._ctx, C.c_void_p(d_img.data_ptr()), C.c_int(w), C.c_int(h),
+                                               C.c_int(kernel), C.c_float(h_loc), C.c_float(h_val),
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()), C.byref(alpha)),
+                    "EntireComputation")
+        self.stream.synchronize()
+        return out, zf, alpha.value
 
     def image_processing(self, d_img, opt=None, want_float=False, out=None):
         """Whole approximate path (hpc/image_processing.c:183-277) on a device image tensor."""

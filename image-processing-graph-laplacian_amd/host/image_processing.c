@@ -6,6 +6,7 @@
  *
  *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
+ * -no_approx runs the full-matrix mode (hpc/image_processing.c:155-181); -use_slepc is accepted and refused.
  *
  * The approximate path runs the tail the reference left commented out
  * (hpc/image_processing.c:240-275) as its specification (survey quirk Q1).
@@ -163,6 +164,40 @@ fail:
     return NULL;
 }
 
+/* EntireComputation, hpc/image_processing.c:155-181 (-no_approx): full N x N affinity and Laplacian,
+ * z = clamp(y - L y). The matrices are never stored (glf_EntireComputation). */
+static png_bytep *EntireComputation(png_bytep *img_bytes, unsigned width, unsigned height)
+{
+    glf_ctx *ctx = glf_world();
+    const size_t n = (size_t)width * height;
+    void *d_img = NULL, *d_out = NULL;
+    uint8_t *flat = (uint8_t *)malloc(n);
+    png_bytep *rows = NULL;
+    if (!flat || glf_malloc(ctx, &d_img, n) != GLF_OK || glf_malloc(ctx, &d_out, n) != GLF_OK) goto out;
+    for (unsigned r = 0; r < height; ++r) memcpy(flat + (size_t)r * width, img_bytes[r], width);
+    if (glf_memcpy_h2d(ctx, d_img, flat, n) != GLF_OK) goto out;
+    const double t = wtime();
+    printf("Computing entire affinity matrix, Laplacian matrix and output image (matrices not stored)... ");
+    const int rc = glf_EntireComputation(ctx, (const uint8_t *)d_img, (int)width, (int)height, GLF_KERNEL_BILATERAL, 40.0f, 30.0f,
+                                         (uint8_t *)d_out, NULL, NULL);
+    if (rc != GLF_OK) {
+        fprintf(stderr, "\nglf_EntireComputation: %s (%s)\n", glf_strerror(rc), glf_ctx_last_error(ctx));
+        goto out;
+    }
+    printf("%fs\n", wtime() - t);
+    if (glf_memcpy_d2h(ctx, flat, d_out, n) != GLF_OK) goto out;
+    rows = (png_bytep *)malloc(sizeof(png_bytep) * height);
+    for (unsigned r = 0; rows && r < height; ++r) {
+        rows[r] = (png_bytep)malloc(width);
+        memcpy(rows[r], flat + (size_t)r * width, width);
+    }
+out:
+    free(flat);
+    if (d_img) glf_free(ctx, d_img);
+    if (d_out) glf_free(ctx, d_out);
+    return rows;
+}
+
 /* Same path through the single fused entry point (no stage materialisation:
  * Phi is written in raster order directly and K_A is never stored). */
 static png_bytep *FusedComputation(png_bytep *img_bytes, unsigned width, unsigned height)
@@ -230,8 +265,7 @@ int main(int argc, char **argv)
 
     int status = 0;
     if (opt_has("-no_approx")) { /* :294-297 */
-        fprintf(stderr, "-no_approx (full N x N matrices) is not part of this build (SURVEY 8f, next row f2)\n");
-        status = 3;
+        output_img = EntireComputation(img_bytes, (unsigned)width, (unsigned)height);
     } else if (opt_has("-fused")) {
         output_img = FusedComputation(img_bytes, (unsigned)width, (unsigned)height);
     } else {

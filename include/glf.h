@@ -258,6 +258,13 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt, const uint8_t *d_
                          int height, uint8_t *d_out, float *d_zf, double *eigvals_out,
                          glf_stats *stats);
 
+/* EntireComputation, hpc/image_processing.c:155-181 (-no_approx): z = clamp(y - L y) with the full N x N
+ * Laplacian of ComputeEntireAffinityMatrix / ComputeEntireLaplacianMatrix / ComputeResultFromEntireLaplacian
+ * (hpc/affinity.c:264-336, hpc/laplacian.c:44-65, hpc/display.c:128-149). The matrices are never stored
+ * ((L y)_i = alpha (D_i y_i - (K y)_i)); O(N^2) work, limited to 4 Mpixel. d_zf, alpha_out optional. */
+int glf_EntireComputation(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int kernel, float h_loc, float h_val,
+                          uint8_t *d_out, float *d_zf, double *alpha_out);
+
 /* ---- image I/O (host) -------------------------------------------------------------- */
 /* int read_png(const char*, png_bytep** rows, int* w, int* h)  hpc/read_img.h:3, hpc/read_img.c:9-65
  * rows: malloc'd array of `height` malloc'd rows of `width` bytes (gray 8);

@@ -383,3 +383,19 @@ def test_exact_zero_skipping_is_bit_identical(ctx):
     assert i0["degree_evaluated"] == dense
     assert i1["degree_evaluated"] < 0.9 * dense
     assert i0["alpha"] == i1["alpha"]                                    # D_A identical to the last bit
+
+
+@pytest.mark.parametrize("shape", [(32, 32), (53, 37), (100, 100), (128, 96)])
+def test_entire_computation_no_approx(ctx, png, shape):
+    """-no_approx (hpc/image_processing.c:155-181): z = clamp(y - L y) with the full N x N Laplacian,
+    against the fp64 oracle (which is itself checked against numpy in tests/test_oracle_golden.py)."""
+    w, h = shape
+    img = png("test.png") if shape == (100, 100) else glf.synth_image(w, h, seed=2)
+    zf_ref, out_ref = orc.entire_computation(img)
+    out, zf, alpha = ctx.EntireComputation(ctx.to_device(img))
+    out, zf = out.cpu().numpy(), zf.cpu().numpy()
+    np.testing.assert_allclose(zf, zf_ref, rtol=0, atol=2e-3)          # D_i y_i ~ 1e5: f32 output rounding
+    assert np.mean(out != out_ref) < 2e-3
+    assert np.abs(out.astype(int) - out_ref.astype(int)).max() <= 1
+    # the approximate path tends to it as samples and eigenpairs grow (sanity, loose)
+    assert 0 < alpha < 1

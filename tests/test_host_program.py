@@ -63,8 +63,11 @@ def test_default_num_eigvals_and_flag_fallbacks(tmp_path, png):
     assert ("Computing %d smallest eigenvalues... (epsilon: 0.2)" % (p - 1)) in r.stdout.decode()
     _, out_ref, _ = orc.image_processing(img, 20, p - 1, epsilon=0.2, inner_rtol=1e-5, seed=1)
     assert psnr(glf.read_png(str(tmp_path / "results" / "output.png")), out_ref) >= 50.0
-    # unsupported modes are refused loudly, not silently ignored
+    # -no_approx: full-matrix mode z = clamp(y - L y) (hpc/image_processing.c:155-181)
     r2 = _run(["-f", TEST_PNG, "-no_approx"], str(tmp_path))
-    assert r2.returncode != 0 and b"-no_approx" in r2.stderr
+    assert r2.returncode == 0, r2.stderr.decode()
+    _, exact_ref = orc.entire_computation(img)
+    exact = glf.read_png(str(tmp_path / "results" / "output.png"))
+    assert np.mean(exact != exact_ref) < 2e-3 and np.abs(exact.astype(int) - exact_ref.astype(int)).max() <= 1
     r3 = _run(["-f", str(tmp_path / "nope.png")], str(tmp_path))
     assert r3.returncode == 1
