@@ -719,10 +719,11 @@ int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, 
 // Classical Gram-Schmidt (hpc/gram_schmidt.c:29-64), column k at a time
 // =====================================================================================
 
-// Two launches per column. The projection proj_u(v) = <v,u>/<u,u> u (hpc/gram_schmidt.c:11-21) does
-// not depend on the length of u, so the columns stay un-normalised during the sweep (q[j] = <u_j,u_j>
+// Three short launches per column. The projection proj_u(v) = <v,u>/<u,u> u (hpc/gram_schmidt.c:11-21)
+// does not depend on the length of u, so the columns stay un-normalised during the sweep (q[j] = <u_j,u_j>
 // is kept instead) and one final pass applies VecNormalize (:59) to all of them; norms[k] = sqrt(q[k])
 // is the same pre-normalisation norm the reference returns.
+constexpr int GS_ROWS = 128; // rows per Gram-Schmidt workgroup (667 workgroups at p = 85 264)
 
 // partial[blk][j] = sum_{i in blk} X[i][k] X[i][j]   (j < k)
 __global__ __launch_bounds__(256) void k_gs_dots(const float *__restrict__ X, unsigned n, unsigned ld, unsigned k,
@@ -730,71 +731,81 @@ __global__ __launch_bounds__(256) void k_gs_dots(const float *__restrict__ X, un
 {
     __shared__ double sh[256];
     const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
-    double v[1] = {0.0};
-    const unsigned base = blockIdx.x * RED_ROWS;
+    double v = 0.0;
+    const unsigned base = blockIdx.x * GS_ROWS;
     if (col < (int)k) {
-        for (unsigned r = rl; r < RED_ROWS; r += nrl) {
+#pragma unroll 4
+        for (unsigned r = rl; r < GS_ROWS; r += nrl) {
             const unsigned i = base + r;
             if (i >= n) break;
-            v[0] += (double)X[(size_t)i * ld + k] * (double)X[(size_t)i * ld + col];
+            v += (double)X[(size_t)i * ld + k] * (double)X[(size_t)i * ld + col];
         }
     }
-    block_col_reduce<1>(v, ld, partial, sh);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < ld) {
+        double t = 0.0;
+        for (int r = 0; r < nrl; ++r) t += sh[r * ld + col];
+        partial[(size_t)blockIdx.x * ld + col] = t;
+    }
 }
 
-// x_k <- x_k - sum_{j<k} coef[j] u_j with coef[j] = (sum_blk partial[blk][j]) / q[j]  (VecAXPBY :53);
-// normpart[k][blk] = sum_{i in blk} x_k[i]^2. Every workgroup rebuilds coef (and q[k-1], which
-// workgroup 0 also publishes) from the partial buffers in a fixed order.
-__global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned k, int nblk,
-                                                   const double *__restrict__ partial, double *__restrict__ q,
-                                                   double *__restrict__ normpart)
+// One workgroup per column j < k: coef[j] = (sum_blk partial[blk][j]) / q[j]; the workgroup of column k-1 first
+// closes q[k-1] = sum_blk normpart[k-1][blk]. With k == m (after the last column) only q[m-1] is closed.
+__global__ __launch_bounds__(256) void k_gs_fin(const double *__restrict__ partial, const double *__restrict__ normpart, int nblk,
+                                                 unsigned ld, unsigned k, unsigned m, double *__restrict__ q,
+                                                 float *__restrict__ coef)
 {
     __shared__ double sh[256];
-    __shared__ float coef[256];
-    __shared__ double qprev;
     const int t = threadIdx.x;
-    // q[k-1] = sum_blk normpart[k-1][blk]
-    if (k > 0) {
+    const unsigned j = blockIdx.x;
+    double qj;
+    if (j + 1 == k) {
         double s = 0.0;
-        for (int b = t; b < nblk; b += 256) s += normpart[(size_t)(k - 1) * nblk + b];
+        for (int b = t; b < nblk; b += 256) s += normpart[(size_t)j * nblk + b];
         sh[t] = s;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
             if (t < o) sh[t] += sh[t + o];
             __syncthreads();
         }
-        if (t == 0) {
-            qprev = sh[0];
-            if (blockIdx.x == 0) q[k - 1] = sh[0];
-        }
+        qj = sh[0];
+        if (t == 0) q[j] = qj;
+        __syncthreads();
+    } else {
+        qj = q[j];
+    }
+    if (k >= m && j + 1 == k) return; // closing call: no projection follows (uniform per workgroup)
+    double s = 0.0;
+    for (int b = t; b < nblk; b += 256) s += partial[(size_t)b * ld + j];
+    sh[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
         __syncthreads();
     }
-    // coef[j], j < k: column j's partials summed by 256/ld row lanes, then combined
-    {
-        const int col = t % ld, rl = t / ld, nrl = 256 / ld;
-        double s = 0.0;
-        if (col < (int)k)
-            for (int b = rl; b < nblk; b += nrl) s += partial[(size_t)b * ld + col];
-        __syncthreads();
-        sh[t] = s;
-        __syncthreads();
-        if (t < (int)ld) {
-            double d = 0.0;
-            for (int r = 0; r < nrl; ++r) d += sh[r * ld + col];
-            const double qq = (col + 1 == (int)k) ? qprev : (col < (int)k ? q[col] : 0.0);
-            coef[col] = (col < (int)k && qq != 0.0) ? (float)(d / qq) : 0.f;
-        }
-        __syncthreads();
-    }
-    // rows: ld/4 lanes per row, float4 each
+    if (t == 0) coef[j] = qj != 0.0 ? (float)(sh[0] / qj) : 0.f;
+}
+
+// x_k <- x_k - sum_{j<k} coef[j] u_j (VecAXPBY :53); normpart[k][blk] = sum_{i in blk} x_k[i]^2.
+// ld / 4 lanes per row, one float4 each.
+__global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned k, int nblk,
+                                                   const float *__restrict__ coef, double *__restrict__ normpart)
+{
+    __shared__ double sh[256];
+    const int t = threadIdx.x;
     const int lpr = ld / 4, q4 = t % lpr, rl = t / lpr, rpp = 256 / lpr;
-    const float4 c4 = make_float4(coef[4 * q4], coef[4 * q4 + 1], coef[4 * q4 + 2], coef[4 * q4 + 3]);
+    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * q4 + 0 < (int)k) c4.x = coef[4 * q4 + 0];
+    if (4 * q4 + 1 < (int)k) c4.y = coef[4 * q4 + 1];
+    if (4 * q4 + 2 < (int)k) c4.z = coef[4 * q4 + 2];
+    if (4 * q4 + 3 < (int)k) c4.w = coef[4 * q4 + 3];
     const bool owner = (int)(k / 4) == q4;
     double nrm = 0.0;
-    const unsigned base = blockIdx.x * RED_ROWS;
-    for (unsigned r = rl; r < RED_ROWS; r += rpp) {
+    const unsigned base = blockIdx.x * GS_ROWS;
+    for (unsigned r = rl; r < GS_ROWS; r += rpp) {
         const unsigned i = base + r;
-        const bool ok = i < n; // whole row group leaves together only if all rows are past the end
+        const bool ok = i < n;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) x = *reinterpret_cast<const float4 *>(&X[(size_t)i * ld + 4 * q4]);
         float s = x.x * c4.x + x.y * c4.y + x.z * c4.z + x.w * c4.w;
@@ -805,7 +816,6 @@ __global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigne
             nrm += (double)xk * (double)xk;
         }
     }
-    __syncthreads();
     sh[t] = nrm;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -815,23 +825,9 @@ __global__ __launch_bounds__(256) void k_gs_apply(float *__restrict__ X, unsigne
     if (t == 0) normpart[(size_t)k * nblk + blockIdx.x] = sh[0];
 }
 
-// q[m-1] from its partials, norms[j] = sqrt(q[j])
-__global__ void k_gs_norms(const double *__restrict__ normpart, int nblk, unsigned m, double *__restrict__ q,
-                           double *__restrict__ norms)
+__global__ void k_gs_norms(const double *__restrict__ q, unsigned m, double *__restrict__ norms)
 {
-    __shared__ double sh[256];
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int b = t; b < nblk; b += 256) s += normpart[(size_t)(m - 1) * nblk + b];
-    sh[t] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) sh[t] += sh[t + o];
-        __syncthreads();
-    }
-    if (t == 0) q[m - 1] = sh[0];
-    __syncthreads();
-    if (t < (int)m) norms[t] = sqrt(q[t]);
+    if (threadIdx.x < m) norms[threadIdx.x] = sqrt(q[threadIdx.x]);
 }
 
 // column norms only (NormaliseVecs, hpc/gram_schmidt.c:66-77)
@@ -871,16 +867,20 @@ __global__ void k_scale_all(float *__restrict__ X, unsigned n, unsigned ld, unsi
 
 struct GsWork {
     DevBuf<double> partial, norms, q, normpart;
+    DevBuf<float> coef;
     int nblk = 0;
     int init(glf_ctx *ctx, unsigned n, unsigned ld)
     {
-        nblk = (int)ceil_div(n, RED_ROWS);
+        nblk = (int)ceil_div(n, GS_ROWS);
+        // `partial` is also the scratch of normalise_dev (RED_ROWS blocks, fewer)
         GLF_TRY(partial.alloc(ctx, (size_t)nblk * 2 * ld));
         GLF_TRY(norms.alloc(ctx, ld));
         GLF_TRY(q.alloc(ctx, ld));
+        GLF_TRY(coef.alloc(ctx, ld));
         GLF_TRY(normpart.alloc(ctx, (size_t)nblk * ld));
         GLF_HIP(ctx, hipMemsetAsync(norms.p, 0, sizeof(double) * ld, ctx->stream));
         GLF_HIP(ctx, hipMemsetAsync(q.p, 0, sizeof(double) * ld, ctx->stream));
+        GLF_HIP(ctx, hipMemsetAsync(coef.p, 0, sizeof(float) * ld, ctx->stream));
         return GLF_OK;
     }
 };
@@ -889,10 +889,15 @@ static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, uns
 {
     hipStream_t st = ctx->stream;
     for (unsigned k = 0; k < m; ++k) {
-        if (k > 0) hipLaunchKernelGGL(k_gs_dots, dim3(w.nblk), dim3(256), 0, st, X, n, ld, k, w.partial.p);
-        hipLaunchKernelGGL(k_gs_apply, dim3(w.nblk), dim3(256), 0, st, X, n, ld, k, w.nblk, w.partial.p, w.q.p, w.normpart.p);
+        if (k > 0) {
+            hipLaunchKernelGGL(k_gs_dots, dim3(w.nblk), dim3(256), 0, st, X, n, ld, k, w.partial.p);
+            hipLaunchKernelGGL(k_gs_fin, dim3(k), dim3(256), 0, st, w.partial.p, w.normpart.p, w.nblk, ld, k, m, w.q.p, w.coef.p);
+        }
+        hipLaunchKernelGGL(k_gs_apply, dim3(w.nblk), dim3(256), 0, st, X, n, ld, k, w.nblk, w.coef.p, w.normpart.p);
     }
-    hipLaunchKernelGGL(k_gs_norms, dim3(1), dim3(256), 0, st, w.normpart.p, w.nblk, m, w.q.p, w.norms.p);
+    // close q[m-1], then norms and the deferred VecNormalize of every column
+    hipLaunchKernelGGL(k_gs_fin, dim3(m), dim3(256), 0, st, w.partial.p, w.normpart.p, w.nblk, ld, m, m, w.q.p, w.coef.p);
+    hipLaunchKernelGGL(k_gs_norms, dim3(1), dim3(256), 0, st, w.q.p, m, w.norms.p);
     hipLaunchKernelGGL(k_scale_all, dim3((unsigned)ceil_div((int64_t)n * ld, 256)), dim3(256), 0, st, X, n, ld, m, w.norms.p);
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
