@@ -212,6 +212,15 @@ int glf_mat_destroy(glf_ctx *ctx, glf_mat *mat)
     return GLF_OK;
 }
 
+int glf_mat_get_column(glf_ctx *ctx, const glf_mat *mat, int64_t col, float *host_out)
+{
+    if (!ctx || !mat || !host_out || mat->kind != GLF_MAT_DENSE || col < 0 || col >= mat->cols) return GLF_ERR_INVALID;
+    GLF_HIP(ctx, hipMemcpy2DAsync(host_out, sizeof(float), mat->data + col, sizeof(float) * (size_t)mat->ld, sizeof(float),
+                                  (size_t)mat->rows, hipMemcpyDeviceToHost, ctx->stream));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
 void glf_options_default(glf_options *opt)
 {
     if (!opt) return;

@@ -1,16 +1,18 @@
 // eigen.hip -- inverse subspace iteration on L_A (hpc/inverse_power_it.c:86-252) with
 // classical Gram-Schmidt (hpc/gram_schmidt.c:29-64), on flat device buffers.
 //
-// Layout: A = L_A is p x p row-major with lda >= round_up(p,32), lda % 4 == 0 and
-// ZERO padding columns. Vector blocks (X, P, R, AP ...) are [p32][ld] row-major,
-// p32 = round_up(p,32), ld = m rounded up to 32; padding rows/columns are zero
-// and never written. One "Vec" of the reference = one column here.
+// Layout: A = L_A is p x p row-major with lda >= round_up(p,64), lda % 4 == 0 and ZERO padding
+// columns (or, row-sharded over ranks, the column block described by MatShard). Vector blocks
+// (X, P, R, AP ...) are [rows][ld] row-major, rows = p rounded up to 64 (more when sharded, see
+// vec_rows), ld = m rounded up to a power of two in {32..256}; padding rows/columns are zero and
+// never written. One "Vec" of the reference = one column here.
 //
 // Kernels:
-//   k_block_matvec   Y = A X      f32 MFMA 32x32x2, A streamed once from HBM (HBM/MFMA bound)
-//   k_gram           G = X^T Y    f32 MFMA, split over row chunks
-//   k_cg_*           Jacobi-PCG vector updates with per-column scalars (HBM bound, tiny)
-//   k_gs_*           classical Gram-Schmidt column sweeps
+//   k_block_matvec_f16s  Y = A X   split-f16 MFMA, A read through its symmetry, HBM bound (default)
+//   k_block_matvec       Y = A X   f32-input MFMA (GLF_CONTRACT_F32_MFMA), exact f32 operands
+//   k_gram               G = X^T Y f32 MFMA, split over row chunks
+//   k_cg_*               Jacobi-PCG vector updates with per-column scalars
+//   k_gs_*               classical Gram-Schmidt column sweeps
 // All reductions go through fixed-order f64 partial buffers => reproducible.
 #include "glf_internal.hpp"
 
@@ -703,18 +705,6 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
                               : GLF_OK;
 }
 
-int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, unsigned m, unsigned ld, double rtol,
-              int max_it, int *iters)
-{
-    CgWork w;
-    GLF_TRY(w.init(ctx, p, ld));
-    hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, A, lda, p, w.dinv.p);
-    GLF_LAUNCH_CHECK(ctx);
-    int rc = block_pcg_work(ctx, w, A, lda, p, XB, m, ld, rtol, max_it, iters);
-    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return rc;
-}
-
 // =====================================================================================
 // Classical Gram-Schmidt (hpc/gram_schmidt.c:29-64), column k at a time
 // =====================================================================================
@@ -1041,14 +1031,6 @@ static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, u
     for (unsigned c = 0; c < m; ++c) ss += h[c];
     *h_out = std::sqrt(ss);
     return GLF_OK;
-}
-
-int residual_norm(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, unsigned m, unsigned ld,
-                  float * /*AX_scratch*/, double *out)
-{
-    ResWork w;
-    GLF_TRY(w.init(ctx, p, ld));
-    return residual_dev(ctx, w, A, lda, p, X, m, ld, out);
 }
 
 // =====================================================================================

@@ -223,10 +223,6 @@ int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const fl
                  unsigned mld, const MatShard *shard = nullptr);
 int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms);
 int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms);
-int residual_norm(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
-                  unsigned ld, float *AX_scratch, double *out);
-int block_pcg(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, float *XB, unsigned m, unsigned ld,
-              double rtol, int max_it, int *iters);
 int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
                             const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
                             float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats,

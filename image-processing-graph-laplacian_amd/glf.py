@@ -39,7 +39,7 @@ CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
 EXPORTS = [
     "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
     "glf_ctx_device_info", "glf_ctx_set_comm", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
-    "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_Sampling",
+    "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_mat_get_column", "glf_Sampling",
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
     "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",

@@ -6,6 +6,7 @@
  *
  *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
+ *                    [-dump_eigvecs]
  * -no_approx runs the full-matrix mode (hpc/image_processing.c:155-181); -use_slepc is accepted and refused.
  *
  * The approximate path runs the tail the reference left commented out
@@ -145,6 +146,16 @@ static png_bytep *ApproximationComputation(png_bytep *img_bytes, unsigned width,
     MatDestroy(&eigvecs);
     eigvecs = eigvecs_perm;
     if (!eigvecs) goto fail;
+
+    if (opt_has("-dump_eigvecs")) { /* the diagnostics of hpc/image_processing.c:252-260 */
+        char name[128];
+        for (unsigned k = 0; k < 3 && k < m; ++k) {
+            snprintf(name, sizeof(name), "results/eigenvector_%u_laplacian.txt", k);
+            WriteMatCol(eigvecs, k, name);
+            snprintf(name, sizeof(name), "results/eigenvector_%u_laplacian.png", k);
+            WritePngMatCol(eigvecs, k, width, height, name);
+        }
+    }
 
     Mat f_eigvals = MatPow(eigvals, 6); /* :263, a no-op in the reference */
     MatDestroy(&eigvals);

@@ -192,3 +192,45 @@ int WriteDiagMat(Mat x, const char *filename)
     free(h);
     return 0;
 }
+
+/* WriteMatCol (hpc/display.c:85-100): one column as text, one value per line. */
+int WriteMatCol(Mat x, unsigned int col_num, const char *filename)
+{
+    const size_t n = (size_t)x->rows;
+    float *h = (float *)malloc(sizeof(float) * n);
+    if (!h || glf_mat_get_column(g_world, x, col_num, h) != GLF_OK) { free(h); return -1; }
+    FILE *f = fopen(filename, "w");
+    if (!f) { free(h); return -1; }
+    for (size_t i = 0; i < n; ++i) fprintf(f, "%.9g\n", (double)h[i]);
+    fclose(f);
+    free(h);
+    return 0;
+}
+
+/* WritePngMatCol (hpc/display.c:102-126): the column as an image through the same (png_byte) cast as the
+ * output image (OneColMat2pngbytes, hpc/utils.c:525; no scaling in the reference either). The reference
+ * selects the column with GetFirstCols(x, col_num), i.e. zero columns for col_num = 0 (survey quirk Q11);
+ * here column col_num is taken. */
+int WritePngMatCol(Mat x, unsigned int col_num, unsigned int width, unsigned int height, const char *filename)
+{
+    const size_t n = (size_t)width * height;
+    if ((size_t)x->rows != n) return -1;
+    float *h = (float *)malloc(sizeof(float) * n);
+    png_bytep *rows = (png_bytep *)malloc(sizeof(png_bytep) * height);
+    int rc = -1;
+    if (h && rows && glf_mat_get_column(g_world, x, col_num, h) == GLF_OK) {
+        png_byte *flat = (png_byte *)malloc(n);
+        if (flat) {
+            for (size_t i = 0; i < n; ++i) {
+                float v = h[i] > 255.f ? 255.f : h[i];
+                flat[i] = (png_byte)(v > 0.f ? v : 0.f);
+            }
+            for (unsigned int r = 0; r < height; ++r) rows[r] = flat + (size_t)r * width;
+            rc = write_png(filename, rows, width, height);
+            free(flat);
+        }
+    }
+    free(rows);
+    free(h);
+    return rc;
+}

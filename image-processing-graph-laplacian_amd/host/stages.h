@@ -43,6 +43,9 @@ Mat Nystroem(Mat B, Mat phi_A, Mat Pi_A_Inv, unsigned int N, unsigned int n, uns
 png_bytep *ComputeResultFromLaplacian(const png_bytep *img_bytes, Mat phi, Mat Pi, unsigned int width,
                                       unsigned int height);
 int WriteDiagMat(Mat x, const char *filename);
+/* hpc/display.h:10-11 (diagnostics of the commented tail, hpc/image_processing.c:252-260) */
+int WriteMatCol(Mat x, unsigned int col_num, const char *filename);
+int WritePngMatCol(Mat x, unsigned int col_num, unsigned int width, unsigned int height, const char *filename);
 
 const glf_eig_stats *LastEigStats(void);
 

@@ -131,6 +131,8 @@ typedef struct glf_mat {
 int glf_mat_create_dense(glf_ctx *ctx, glf_mat *mat, int64_t rows, int64_t cols, int64_t ld);
 int glf_mat_create_diag(glf_ctx *ctx, glf_mat *mat, int64_t n);
 int glf_mat_destroy(glf_ctx *ctx, glf_mat *mat); /* MatDestroy */
+/* MatGetColumnVector (hpc/display.c:95): column `col` of a dense matrix into host_out[rows]. */
+int glf_mat_get_column(glf_ctx *ctx, const glf_mat *mat, int64_t col, float *host_out);
 
 /* ---- host-side stages -------------------------------------------------------- */
 

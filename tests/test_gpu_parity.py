@@ -399,3 +399,21 @@ def test_entire_computation_no_approx(ctx, png, shape):
     assert np.abs(out.astype(int) - out_ref.astype(int)).max() <= 1
     # the approximate path tends to it as samples and eigenpairs grow (sanity, loose)
     assert 0 < alpha < 1
+
+
+@pytest.mark.parametrize("w,h,ns,m", [(16, 12, 6, 2), (24, 31, 9, 3), (200, 160, 500, 128), (256, 256, 655, 256)])
+def test_extreme_shapes_end_to_end(ctx, w, h, ns, m):
+    """Tiny images (p < one 64-sample chunk) and the widest supported blocks (ld = 128, 256: the MB = 4 / 8
+    kernel instantiations) against the oracle. m = 256 is the stated upper limit of this build."""
+    img = glf.synth_image(w, h, seed=21)
+    eps = 0.2
+    zf_ref, out_ref, ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
+    opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    out, zf = out.cpu().numpy(), zf.cpu().numpy()
+    assert (info["p"], info["m"]) == (ref["p"], ref["m"])
+    assert info["alpha"] == pytest.approx(ref["alpha"], rel=2e-6)
+    assert abs(info["outer_its"] - ref["outer_its"]) <= 1
+    if info["outer_its"] == ref["outer_its"]:
+        assert np.linalg.norm(zf - zf_ref) / np.linalg.norm(zf_ref) <= 1e-4
+        assert psnr(out, out_ref) >= 50.0

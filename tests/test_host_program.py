@@ -53,6 +53,24 @@ def test_image_processing_on_test_png(tmp_path, png, extra):
 
 
 @pytest.mark.gpu
+def test_eigenvector_dumps(tmp_path, png):
+    """-dump_eigvecs: the diagnostics of the reference's commented tail (hpc/image_processing.c:252-260)."""
+    r = _run(["-f", TEST_PNG, "-num_eigvals", "8", "-dump_eigvecs"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()
+    img = png("test.png")
+    idx = orc.sampling(100, 100, 100)
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    LA, alpha = orc.laplacian(KA, orc.degree(img, idx))
+    vecs, vals, _ = orc.inverse_power_iteration(LA, 8, orc.random_vectors(100, 8, 1), epsilon=0.1, inner_rtol=1e-5)
+    phi = orc.permutation(orc.nystroem(img, idx, alpha, vecs, vals), idx)
+    for k in range(3):
+        col = np.loadtxt(str(tmp_path / "results" / ("eigenvector_%d_laplacian.txt" % k)))
+        assert col.shape == (10000,)
+        np.testing.assert_allclose(col, phi[k], rtol=0, atol=2e-3 * np.abs(phi[k]).max())
+        assert glf.read_png(str(tmp_path / "results" / ("eigenvector_%d_laplacian.png" % k))).shape == (100, 100)
+
+
+@pytest.mark.gpu
 def test_default_num_eigvals_and_flag_fallbacks(tmp_path, png):
     # no -num_eigvals -> p - 1 with the reference's stderr note (hpc/image_processing.c:96-108); -opti_gs 0 -> 1
     r = _run(["-f", TEST_PNG, "-num_samples", "20", "-opti_gs", "0", "-inv_it_epsilon", "0.2"], str(tmp_path))
