@@ -102,20 +102,25 @@ def cpu_baseline(img, info, args):
     }
 
 
-def parity_check(ctx):
-    """PSNR of the HIP output against the fp64 oracle on BASELINE config 2 (barbara 512x512, 1 %,
-    m = 64): the 4096^2 oracle run would take about an hour of CPU, this one ~15 s."""
+def cpu_parity_cfg2(ctx):
+    """Second half of the cpu_baseline leg: the oracle's WHOLE path on BASELINE config 2 (barbara
+    512x512, 1 %, m = 64; ~15 s of CPU, the 4096^2 run would take about two hours), timed, and used as the
+    checker of the HIP output on the same input: PSNR on the 8-bit images, rel-L2 on the floats."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     from PIL import Image
     img = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "barbara.png")))
     opt = glf.default_options(num_samples=2621, num_eigvals=64, epsilon=0.1)
     out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    t0 = time.time()
     zf_ref, out_ref, ref = orc.image_processing(img, 2621, 64, epsilon=0.1, inner_rtol=1e-5, seed=1)
+    cpu_s = time.time() - t0
     out, zf = out.cpu().numpy(), zf.cpu().numpy()
     mse = float(np.mean((out.astype(np.float64) - out_ref) ** 2))
     return {
         "workload": "barbara.png 512x512, 1% samples (p=2601), m=64, eps=0.1 vs fp64 oracle",
+        "cpu_seconds": round(cpu_s, 2), "cpu_mpixel_per_s": round(img.size / cpu_s * 1e-6, 5),
+        "gpu_ms": round(info["ms_total"], 3),
         "psnr_db": None if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2),
         "identical_u8": mse == 0,
         "rel_l2_float": float(np.linalg.norm(zf - zf_ref) / np.linalg.norm(zf_ref)),
@@ -247,8 +252,8 @@ def main():
             }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, info, args)
-        if n_gpus == 1 and not args.no_parity:
-            line["parity"] = parity_check(ctx)
+        if n_gpus == 1 and not args.no_parity and "cpu_baseline" in line:
+            line["cpu_baseline"]["parity_cfg2"] = cpu_parity_cfg2(ctx)
         print(json.dumps(line))
     ctx.close()
     if world > 1:
