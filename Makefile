@@ -6,7 +6,7 @@ ARCH     ?= gfx950
 PKG      := image-processing-graph-laplacian_amd
 CSRC     := $(PKG)/csrc
 HOST     := $(PKG)/host
-HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -ffp-contract=fast
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -ffp-contract=fast -fno-slp-vectorize
 CFLAGS   ?= -O2 -std=gnu11 -Wall -Wextra -fPIC
 
 HIP_SRCS := $(CSRC)/ctx.hip $(CSRC)/affinity.hip $(CSRC)/eigen.hip $(CSRC)/nystroem.hip \

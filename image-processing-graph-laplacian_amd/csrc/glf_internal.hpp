@@ -151,17 +151,23 @@ __device__ __forceinline__ void lds_dma_16B(const void *gptr, unsigned lds_byte_
                  : "memory");
 }
 __device__ __forceinline__ void lds_dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// f32 at an absolute LDS byte address (ds_read_b32 with a computed address)
+__device__ __forceinline__ float lds_f32(unsigned lds_byte_addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) float *>(lds_byte_addr);
+}
 __device__ __forceinline__ unsigned lds_offset_of(const void *lds_ptr)
 {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)(const char *)lds_ptr;
 }
-// copy `pieces` KiB-sized pieces global -> LDS, piece i handled by wave (i % 4) of a 256-thread workgroup
+// copy `pieces` KiB-sized pieces global -> LDS, piece i handled by wave (i % NW) of an NW-wave workgroup
+template <int NW = 4>
 __device__ __forceinline__ void lds_dma_copy(const void *gsrc, void *ldst, int pieces, int wave, int lane)
 {
     const char *g = reinterpret_cast<const char *>(gsrc);
     const unsigned base = lds_offset_of(ldst);
     const int uw = __builtin_amdgcn_readfirstlane(wave);
-    for (int i = uw; i < pieces; i += 4) lds_dma_16B(g + (size_t)i * 1024 + lane * 16, base + (unsigned)i * 1024u);
+    for (int i = uw; i < pieces; i += NW) lds_dma_16B(g + (size_t)i * 1024 + lane * 16, base + (unsigned)i * 1024u);
 }
 
 // ---- stage implementations (device pointers, all on ctx->stream) -----------------
@@ -235,7 +241,7 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float scale, const float *d_psi, unsigned m, unsigned ld,
                       float *d_phi, int raster, double *d_c, float *kernel_ms, int window = 0,
-                      uint64_t *chunks_visited = nullptr);
+                      uint64_t *entries_evaluated = nullptr);
 // box[c] = {rmin, rmax, cmin, cmax} of samples [64 c, 64 c + 64) (nystroem.hip)
 int chunk_boxes(glf_ctx *ctx, const float4 *d_samples, unsigned p, int4 *d_box);
 // Phi rows of the sample pixels <- Phi_A rows (hpc/nystroem.c:25-34 + hpc/utils.c:149-152)

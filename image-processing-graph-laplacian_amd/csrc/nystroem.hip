@@ -44,6 +44,8 @@ __device__ __forceinline__ unsigned samples_before(const uint32_t *__restrict__ 
 // comes within `radius` of its pixels' bounding box.
 // ---------------------------------------------------------------------------------------------
 constexpr int NYS_MAXCH = 4096; // chunks a workgroup can list (p <= 262 144); more -> dense on the host side
+constexpr int NYS_MAXCH_LUT = 2048; // the LUT kernel has less LDS to spare
+constexpr int NYS_LUT_RMAX = 511;   // largest half-width of the spatial factor table
 
 // box[chunk] = {rmin, rmax, cmin, cmax} over the chunk's valid samples
 __global__ void k_chunk_boxes(const float4 *__restrict__ samples, unsigned p, int4 *__restrict__ box)
@@ -63,10 +65,12 @@ __global__ void k_chunk_boxes(const float4 *__restrict__ samples, unsigned p, in
 
 // Returns the number of listed chunks (all of them, identity order, when radius < 0).
 __device__ __forceinline__ int build_chunk_list(const int4 *__restrict__ box, int nchunks, int radius, int width,
-                                                int64_t wg_first, int64_t wg_last, int *clist, int *scratch /* [257] */)
+                                                int64_t wg_first, int64_t wg_last, unsigned short *clist,
+                                                int *scratch /* [257] */)
 {
     if (radius < 0) return nchunks;
     const int t = threadIdx.x;
+    const bool lister = t < 256; // workgroups may be wider than the 256 listing threads
     const int r_lo = (int)(wg_first / width), r_hi = (int)(wg_last / width);
     const int c_lo = (r_lo == r_hi) ? (int)(wg_first % width) : 0;
     const int c_hi = (r_lo == r_hi) ? (int)(wg_last % width) : width - 1;
@@ -75,20 +79,20 @@ __device__ __forceinline__ int build_chunk_list(const int4 *__restrict__ box, in
     int count = 0;
     for (int i = 0; i < per; ++i) {
         const int ch = t * per + i;
-        if (ch < nchunks) {
+        if (lister && ch < nchunks) {
             const int4 b = box[ch];
             const bool rel = b.y >= r_lo - radius && b.x <= r_hi + radius && b.w >= c_lo - radius && b.z <= c_hi + radius;
             bits |= (unsigned)rel << i;
             count += rel;
         }
     }
-    scratch[t] = count;
+    if (lister) scratch[t] = count;
     __syncthreads();
     int off = 0;
-    for (int k = 0; k < t; ++k) off += scratch[k];
+    for (int k = 0; k < min(t, 256); ++k) off += scratch[k];
     if (t == 255) scratch[256] = off + count;
     for (int i = 0; i < per; ++i)
-        if (bits & (1u << i)) clist[off++] = t * per + i;
+        if (bits & (1u << i)) clist[off++] = (unsigned short)(t * per + i);
     __syncthreads();
     return scratch[256];
 }
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_nystroem(const uint8_t *__restrict__ im
 {
     constexpr int LD = MB * 32;
     constexpr int KC = NYS_KC;
-    __shared__ int clist[SKIP ? NYS_MAXCH : 1];
+    __shared__ unsigned short clist[SKIP ? NYS_MAXCH : 1];
     __shared__ int cscratch[SKIP ? 257 : 1];
     // one array for everything (guide: a second __shared__ object can de-pipeline LDS staging)
     __shared__ __attribute__((aligned(16))) float lds[2 * (NYS_KC * 4 + NYS_KC * MB * 32)];
@@ -275,12 +279,13 @@ struct NysWindow {
     DevBuf<int4> box;
     DevBuf<unsigned> visited;
     int radius = -1;
-    int init(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef, int window, double t_zero, int64_t nwg)
+    int init(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef, int window, double t_zero, int64_t nwg,
+             int max_chunks = NYS_MAXCH)
     {
         const unsigned nchunks = (unsigned)ceil_div(p, 64);
         radius = -1;
         // K < 2^-t_zero is exactly zero for the contraction; t >= s_loc * d^2 for a row or column distance d
-        if (window && coef.s_loc > 0.f && nchunks <= (unsigned)NYS_MAXCH)
+        if (window && coef.s_loc > 0.f && nchunks <= (unsigned)max_chunks)
             radius = (int)std::floor(std::sqrt(t_zero / (double)coef.s_loc)) + 1;
         GLF_TRY(box.alloc(ctx, nchunks));
         GLF_TRY(visited.alloc(ctx, (size_t)nwg));
@@ -304,7 +309,7 @@ template <int MB, int PB>
 static int launch_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int64_t pix0, int64_t pix1,
                            const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                            KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms,
-                           int window, uint64_t *chunks_visited)
+                           int window, uint64_t *entries_evaluated)
 {
     constexpr int LD = MB * 32;
     const int64_t npix = pix1 - pix0;
@@ -325,7 +330,10 @@ static int launch_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int64_
                            win.box.p, win.radius, win.visited.p);
     GLF_LAUNCH_CHECK(ctx);
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-    if (chunks_visited) GLF_TRY(win.total(ctx, nwg, chunks_visited));
+    if (entries_evaluated) { // listed chunks x 64 samples x the workgroup's pixels
+        GLF_TRY(win.total(ctx, nwg, entries_evaluated));
+        *entries_evaluated *= 64ull * (4 * 32 * PB);
+    }
     if (d_c) GLF_TRY(sum_rows(ctx, cpart.p, nwg, LD, d_c, true));
     if (kernel_ms) {
         GLF_HIP(ctx, hipEventSynchronize(ctx->ev[7]));
@@ -380,7 +388,7 @@ __global__ void k_samples_soa(const float4 *__restrict__ samples, unsigned p_pad
     o[0] = v.x;
     o[64] = v.y;
     o[128] = v.z;
-    o[192] = 0.f;
+    o[192] = __int_as_float(128 * (int)v.z); // value * (32 banks * 4 B): row stride of the LUT kernel's photometric table
 }
 
 __global__ void k_col_absmax(const float *__restrict__ psi, unsigned p, unsigned ld, float *__restrict__ out)
@@ -398,27 +406,57 @@ __global__ void k_col_absmax(const float *__restrict__ psi, unsigned p, unsigned
     if (threadIdx.x == 0) out[c] = sh[0];
 }
 
-template <int MB, int PB, bool SKIP>
-__global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict__ img, int width, int64_t pix0, int64_t pix1,
+// |a - b| + c in one instruction (hipcc expands __usad into max/min/sub/add)
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// LUT = true generates K' without transcendental instructions. The bilateral kernel factors as
+//   K' = [2^15 exp2(-s_loc dr^2)] * exp2(-s_loc dc^2) * exp2(-s_val dv^2) = Er(dr) * Ec(dc) * P(|dv|)
+// and, with u8 pixel values and integer coordinates, each factor takes few distinct values:
+//   P   256 entries, gathered per entry from a copy replicated over the 32 ds_read_b32 banks
+//       (lane l reads bank l % 32: conflict-free whatever the pixel values are);
+//       -- the address is one v_sad_u32: |128 pv - 128 sv| + (plut + 4 (l % 32));
+//   Ec  2 (R + 32) + 1 entries, R = the distance at which the factor is exactly 0 in f32. A block of 32
+//       consecutive pixels lies in one image row (width % 32 == 0), so its lanes read 32 consecutive
+//       entries from a per-(block, sample) base; the base is clamped once per (wave, block, chunk) into
+//       the zero margins of the table, and the per-entry address is one v_add_u32;
+//   Er  the same factor with the 2^15 folded in, gathered once per (wave, block, chunk) likewise.
+// The tables are correctly rounded from f64 on the host, so K' carries three roundings (< 2 ulp).
+// Per entry: 4 VALU + 2 ds_read_b32 instead of 9 VALU + v_exp_f32, then the same 2 VALU f16 split.
+// NW = waves per workgroup: 4, or 6 for the LUT kernel (its 74 KiB of LDS allow two workgroups per CU; six
+// waves each make that three waves per SIMD, which the gather latency needs).
+template <int MB, int PB, bool SKIP, bool LUT, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 1, NW == 8 ? 4 : 8))) void k_nystroem_f16s(const uint8_t *__restrict__ img, int width, int64_t pix0, int64_t pix1,
                                                         const float *__restrict__ soa, unsigned p, float s_loc, float s_val,
                                                         const _Float16 *__restrict__ psi16, const float *__restrict__ invscale,
                                                         float *__restrict__ phi, int raster,
                                                         const uint8_t *__restrict__ mask, const uint32_t *__restrict__ idx,
                                                         double *__restrict__ cpartial, const int4 *__restrict__ chunk_box,
-                                                        int radius, unsigned *__restrict__ visited)
+                                                        int radius, unsigned *__restrict__ visited,
+                                                        const float *__restrict__ lut, int lut_r)
 {
     constexpr int LD = MB * 32;
-    __shared__ int clist[SKIP ? NYS_MAXCH : 1];
+    __shared__ unsigned short clist[SKIP ? (LUT ? NYS_MAXCH_LUT : NYS_MAXCH) : 1];
     __shared__ int cscratch[SKIP ? 257 : 1];
+    // LUT generation (see the header comment of this kernel)
+    __shared__ float plut[LUT ? 256 * 32 : 1];
+    __shared__ float elut[LUT ? 2 * (NYS_LUT_RMAX + 32 * PB) + 1 : 1];
+    __shared__ __attribute__((aligned(16))) float erw[LUT ? NW * 64 : 4];
+    __shared__ __attribute__((aligned(16))) unsigned cbw[LUT ? NW * 64 : 4];
     constexpr int PSI_F4 = 4 * MB * 2 * 64;      // float4 (16 B) words of one chunk's Psi fragments
     constexpr int BUF_F4 = 64 + PSI_F4;          // + 1 KiB sample SoA
     __shared__ __attribute__((aligned(16))) float4 lds[2 * BUF_F4];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5;
-    const int64_t wbase = pix0 + ((int64_t)blockIdx.x * 4 + wave) * (32 * PB);
+    const int64_t wbase = pix0 + ((int64_t)blockIdx.x * NW + wave) * (32 * PB);
 
     float pr[PB], pc[PB], pv[PB];
+    int pv128[PB]; // LUT: 128 * value
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
         int64_t px = wbase + 32 * b + (lane & 31);
@@ -426,7 +464,21 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
         pr[b] = (float)(px / width);
         pc[b] = (float)(px % width);
         pv[b] = (float)img[px];
+        pv128[b] = 128 * (int)img[px];
     }
+    // LUT: the wave's 32 PB consecutive pixels lie in one image row (host-checked): first column and row
+    const int64_t wfirst = min(wbase, pix1 - 1);
+    const int pcol0 = (int)(wfirst % width), prow = (int)(wfirst / width);
+    const int lut_w = lut_r + 32 * PB, lut_n = 2 * lut_w + 1;
+    const unsigned lane4 = (lane & 31) * 4;
+    const unsigned pbase = LUT ? lds_offset_of(plut) + lane4 : 0;
+    const unsigned ebase = LUT ? lds_offset_of(elut) : 0;
+    if (LUT) {
+        for (int i = threadIdx.x; i < 256 * 32; i += NW * 64) plut[i] = lut[i >> 5];
+        for (int i = threadIdx.x; i < lut_n; i += NW * 64) elut[i] = lut[256 + i];
+        // visible to all waves after the barrier that follows the first stage()
+    }
+    const float *lut_er = lut + 256 + lut_n;
     f32x16 acc[PB][MB];
 #pragma unroll
     for (int b = 0; b < PB; ++b)
@@ -436,8 +488,8 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
             for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
 
     const int nchunks = (int)((p + 63) / 64);
-    const int64_t wg_first = pix0 + (int64_t)blockIdx.x * (128 * PB);
-    const int64_t wg_last = min(wg_first + 128 * PB, pix1) - 1;
+    const int64_t wg_first = pix0 + (int64_t)blockIdx.x * (NW * 32 * PB);
+    const int64_t wg_last = min(wg_first + NW * 32 * PB, pix1) - 1;
     const int nlist = SKIP ? build_chunk_list(chunk_box, nchunks, radius, width, wg_first, wg_last, clist, cscratch) : nchunks;
     if (visited && threadIdx.x == 0) visited[blockIdx.x] = (unsigned)nlist;
     auto chunk_at = [&](int i) { return SKIP ? clist[i] : i; };
@@ -449,7 +501,7 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
     auto stage = [&](int chunk, int buf) {
         float4 *dst = lds + buf * BUF_F4;
         if (wave == 0) lds_dma_16B(reinterpret_cast<const char *>(gsoa + (size_t)chunk * 64) + lane * 16, lds_offset_of(dst));
-        lds_dma_copy(gpsi + (size_t)chunk * PSI_F4, dst + 64, PIECES, wave, lane);
+        lds_dma_copy<NW>(gpsi + (size_t)chunk * PSI_F4, dst + 64, PIECES, wave, lane);
     };
     if (nlist > 0) stage(chunk_at(0), 0);
     lds_dma_drain();
@@ -459,11 +511,37 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
         if (ch + 1 < nlist) stage(chunk_at(ch + 1), buf ^ 1); // in flight during the MFMA/VALU sweep below
         const float *ssoa = reinterpret_cast<const float *>(lds + buf * BUF_F4);
         const f16x8 *sfrag = reinterpret_cast<const f16x8 *>(lds + buf * BUF_F4 + 64);
+        if (LUT) {
+            // Er of sample `lane` for each pixel block of this wave (wave-private LDS slots: the wave
+            // executes its LDS operations in order, no barrier needed)
+            const int srow = (int)ssoa[lane], scol = (int)ssoa[64 + lane];
+            const int d = min(max(prow - srow + lut_w, 0), 2 * lut_w);
+            erw[wave * 64 + lane] = lut_er[d];
+            // lanes add 0 .. 32 PB - 1 to the base: clamped so that they stay inside the table's zero margins
+            const int cb = min(max(pcol0 - scol, -lut_w), lut_r + 1);
+            cbw[wave * 64 + lane] = ebase + 4u * (unsigned)(cb + lut_w);
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // this lane's 8 samples of the step: 16 t + 8 half + (0..7)
             float sr[8], sc[8], sv[8];
-            {
+            unsigned sv128[8], cb[8];
+            float er[8];
+            if (LUT) {
+                const uint4 *qi = reinterpret_cast<const uint4 *>(ssoa + 192 + 16 * t + 8 * half);
+                const uint4 v0 = qi[0], v1 = qi[1];
+                sv128[0] = v0.x; sv128[1] = v0.y; sv128[2] = v0.z; sv128[3] = v0.w;
+                sv128[4] = v1.x; sv128[5] = v1.y; sv128[6] = v1.z; sv128[7] = v1.w;
+                const float4 *qe = reinterpret_cast<const float4 *>(erw + wave * 64 + 16 * t + 8 * half);
+                const float4 e0 = qe[0], e1 = qe[1];
+                er[0] = e0.x; er[1] = e0.y; er[2] = e0.z; er[3] = e0.w;
+                er[4] = e1.x; er[5] = e1.y; er[6] = e1.z; er[7] = e1.w;
+                const uint4 *qc = reinterpret_cast<const uint4 *>(cbw + wave * 64 + 16 * t + 8 * half);
+                const uint4 c0 = qc[0], c1 = qc[1];
+                cb[0] = c0.x; cb[1] = c0.y; cb[2] = c0.z; cb[3] = c0.w;
+                cb[4] = c1.x; cb[5] = c1.y; cb[6] = c1.z; cb[7] = c1.w;
+            } else {
                 const float4 *q = reinterpret_cast<const float4 *>(ssoa + 16 * t + 8 * half);
                 const float4 r0 = q[0], r1 = q[1], c0 = q[16], c1 = q[17], v0 = q[32], v1 = q[33];
                 sr[0] = r0.x; sr[1] = r0.y; sr[2] = r0.z; sr[3] = r0.w; sr[4] = r1.x; sr[5] = r1.y; sr[6] = r1.z; sr[7] = r1.w;
@@ -471,6 +549,13 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                 sv[0] = v0.x; sv[1] = v0.y; sv[2] = v0.z; sv[3] = v0.w; sv[4] = v1.x; sv[5] = v1.y; sv[6] = v1.z; sv[7] = v1.w;
             }
             f16x8 ah[PB], al[PB];
+#ifdef NYS_DBG_NOGEN
+#pragma unroll
+            for (int b = 0; b < PB; ++b)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ah[b][e] = (_Float16)pv[b]; al[b][e] = (_Float16)pc[b]; }
+            if (0)
+#endif
 #pragma unroll
             for (int b = 0; b < PB; ++b) {
 #pragma unroll
@@ -478,12 +563,21 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                     f32x2 y;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const float dr = pr[b] - sr[e + u], dc = pc[b] - sc[e + u], dv = pv[b] - sv[e + u];
-                        const float q = fmaf(dc, dc, dr * dr);
-                        y[u] = __builtin_amdgcn_exp2f(NYS_F16_KSCALE_LOG2 - fmaf(dv * dv, s_val, q * s_loc));
+                        if (LUT) {
+                            const float ec = lds_f32(cb[e + u] + (lane4 + 128u * b));
+                            const float pp = lds_f32(sad_u32((unsigned)pv128[b], sv128[e + u], pbase));
+                            y[u] = (er[e + u] * ec) * pp;
+                        } else {
+                            const float dr = pr[b] - sr[e + u], dc = pc[b] - sc[e + u], dv = pv[b] - sv[e + u];
+                            const float q = fmaf(dc, dc, dr * dr);
+                            y[u] = __builtin_amdgcn_exp2f(NYS_F16_KSCALE_LOG2 - fmaf(dv * dv, s_val, q * s_loc));
+                        }
                     }
                     const f16x2 h2 = __builtin_convertvector(y, f16x2);            // round to nearest
-                    const f32x2 res = y - __builtin_convertvector(h2, f32x2);      // exact in f32
+                    // scalar subtractions on purpose: v_pk_add_f32 is slower than two v_sub_f32 beside MFMAs
+                    f32x2 res;
+                    res[0] = y[0] - (float)h2[0]; // exact in f32
+                    res[1] = y[1] - (float)h2[1];
                     const f16x2 l2 = __builtin_convertvector(res, f16x2);
                     ah[b][e] = h2[0];
                     ah[b][e + 1] = h2[1];
@@ -491,17 +585,25 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
                     al[b][e + 1] = l2[1];
                 }
             }
+            // The two waves of a SIMD drift into lockstep (both generating, then both contracting) unless the
+            // one in its MFMA burst wins the issue arbitration: the other then fills the gaps with its VALU.
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < MB; ++j) {
                 const f16x8 bh = sfrag[((t * MB + j) * 2 + 0) * 64 + lane];
                 const f16x8 bl = sfrag[((t * MB + j) * 2 + 1) * 64 + lane];
 #pragma unroll
                 for (int b = 0; b < PB; ++b) {
+#ifdef NYS_DBG_NOMFMA
+                    asm volatile("" : : "v"(ah[b]), "v"(al[b]), "v"(bh), "v"(bl));
+#else
                     acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bh, acc[b][j], 0, 0, 0);
                     acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bl, acc[b][j], 0, 0, 0);
                     acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b], bh, acc[b][j], 0, 0, 0);
+#endif
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         lds_dma_drain(); // this wave's pieces of the next chunk have landed ...
         __syncthreads(); // ... and so have everybody else's; buffer `buf` is free again
@@ -539,17 +641,20 @@ __global__ __launch_bounds__(256) void k_nystroem_f16s(const uint8_t *__restrict
     }
     if (cpartial) {
         __syncthreads();
-        float *red = reinterpret_cast<float *>(lds); // [4 waves][LD]
+        float *red = reinterpret_cast<float *>(lds); // [NW waves][LD]
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             float v = csum[j] + __shfl_xor(csum[j], 32, 64);
             if (half == 0) red[wave * LD + 32 * j + l31] = v;
         }
         __syncthreads();
-        if (threadIdx.x < LD)
-            cpartial[(size_t)blockIdx.x * LD + threadIdx.x] =
-                ((double)red[threadIdx.x] + (double)red[LD + threadIdx.x]) +
-                ((double)red[2 * LD + threadIdx.x] + (double)red[3 * LD + threadIdx.x]);
+        if (threadIdx.x < LD) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; w += 2)
+                tot += (double)red[w * LD + threadIdx.x] + (double)red[(w + 1) * LD + threadIdx.x];
+            cpartial[(size_t)blockIdx.x * LD + threadIdx.x] = tot;
+        }
     }
 }
 
@@ -557,7 +662,7 @@ template <int MB, int PB>
 static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, int64_t pix0, int64_t pix1,
                                 const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                                 KernelCoef coef, const float *d_psi, float *d_phi, int raster, double *d_c, float *kernel_ms,
-                                int window, uint64_t *chunks_visited)
+                                int window, uint64_t *entries_evaluated)
 {
     constexpr unsigned LD = MB * 32;
     const unsigned p_pad = (unsigned)round_up(p, NYS_PAD);
@@ -593,25 +698,60 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     hipLaunchKernelGGL(k_samples_soa, dim3((p_pad + 255) / 256), dim3(256), 0, st, d_samples, p_pad, soa.p);
     GLF_LAUNCH_CHECK(ctx);
 
+    // Table-driven generation (k_nystroem_f16s<.., LUT = true>): needs each wave's 32 PB pixels inside one image
+    // row, a spatial factor that reaches exact zero within NYS_LUT_RMAX, and LDS for two workgroups per CU.
+    constexpr int NW_LUT = 8;
+    int lut_r = 0;
+    if (MB <= 2 && coef.s_loc > 0.f && width % (32 * PB) == 0 && pix0 % (32 * PB) == 0 && !getenv("GLF_NYS_NO_LUT")) {
+        // exp2(-s d^2) < 2^-150 rounds to +0 in f32
+        lut_r = (int)std::floor(std::sqrt(150.5 / (double)coef.s_loc)) + 1;
+        if (lut_r > NYS_LUT_RMAX) lut_r = 0;
+    }
+    const bool use_lut = lut_r > 0;
+    const int nw = use_lut ? NW_LUT : 4;
     const int64_t npix = pix1 - pix0;
-    const int64_t nwg = ceil_div(npix, 4 * 32 * PB);
+    const int64_t nwg = ceil_div(npix, nw * 32 * PB);
     DevBuf<double> cpart;
     if (d_c) GLF_TRY(cpart.alloc(ctx, (size_t)nwg * LD));
+    std::vector<float> hlut;
+    DevBuf<float> dlut;
+    if (use_lut) {
+        const int lut_w = lut_r + 32 * PB, ne = 2 * lut_w + 1; // 32 PB zero entries of margin on both sides
+        hlut.resize(256 + 2 * (size_t)ne);
+        for (int e = 0; e < 256; ++e) hlut[e] = (float)std::exp2(-(double)coef.s_val * e * e);
+        for (int i = 0; i < ne; ++i) {
+            const double t = (double)coef.s_loc * (double)(i - lut_w) * (double)(i - lut_w);
+            hlut[256 + i] = (float)std::exp2(-t);
+            hlut[256 + ne + i] = (float)std::exp2((double)NYS_F16_KSCALE_LOG2 - t);
+        }
+        GLF_TRY(dlut.alloc(ctx, hlut.size()));
+        GLF_HIP(ctx, hipMemcpyAsync(dlut.p, hlut.data(), sizeof(float) * hlut.size(), hipMemcpyHostToDevice, st));
+    }
     // K' = 2^15 K rounds to zero in f16 (hi and lo) below 2^-25: t > 40; 40.5 covers the f32 rounding of t
     NysWindow win;
-    GLF_TRY(win.init(ctx, d_samples, p, coef, window, 40.5, nwg));
+    GLF_TRY(win.init(ctx, d_samples, p, coef, window, 40.5, nwg, use_lut ? NYS_MAXCH_LUT : NYS_MAXCH));
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[6], st));
-    if (win.radius >= 0)
-        hipLaunchKernelGGL((k_nystroem_f16s<MB, PB, true>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
-                           coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
-                           win.box.p, win.radius, win.visited.p);
-    else
-        hipLaunchKernelGGL((k_nystroem_f16s<MB, PB, false>), dim3((unsigned)nwg), dim3(256), 0, st, d_img, width, pix0, pix1, soa.p, p,
-                           coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx, d_c ? cpart.p : nullptr,
-                           win.box.p, win.radius, win.visited.p);
+#define GLF_NYS_LAUNCH(SKIP_, LUT_, NW_)                                                                                     \
+    hipLaunchKernelGGL((k_nystroem_f16s<MB, PB, SKIP_, LUT_, NW_>), dim3((unsigned)nwg), dim3(NW_ * 64), 0, st, d_img, width, \
+                       pix0, pix1, soa.p, p, coef.s_loc, coef.s_val, psi16.p, invscale.p, d_phi, raster, d_mask, d_idx,      \
+                       d_c ? cpart.p : nullptr, win.box.p, win.radius, win.visited.p, dlut.p, lut_r)
+    if constexpr (MB <= 2) {
+        if (use_lut) {
+            if (win.radius >= 0) GLF_NYS_LAUNCH(true, true, NW_LUT);
+            else GLF_NYS_LAUNCH(false, true, NW_LUT);
+        }
+    }
+    if (!use_lut) {
+        if (win.radius >= 0) GLF_NYS_LAUNCH(true, false, 4);
+        else GLF_NYS_LAUNCH(false, false, 4);
+    }
+#undef GLF_NYS_LAUNCH
     GLF_LAUNCH_CHECK(ctx);
     if (kernel_ms) GLF_HIP(ctx, hipEventRecord(ctx->ev[7], st));
-    if (chunks_visited) GLF_TRY(win.total(ctx, nwg, chunks_visited));
+    if (entries_evaluated) { // listed chunks x 64 samples x the workgroup's pixels
+        GLF_TRY(win.total(ctx, nwg, entries_evaluated));
+        *entries_evaluated *= 64ull * (uint64_t)(nw * 32 * PB);
+    }
     if (d_c) GLF_TRY(sum_rows(ctx, cpart.p, nwg, LD, d_c, true));
     GLF_HIP(ctx, hipStreamSynchronize(st)); // hscale/hinv and the DevBufs go out of scope
     if (kernel_ms) GLF_HIP(ctx, hipEventElapsedTime(kernel_ms, ctx->ev[6], ctx->ev[7]));
@@ -621,7 +761,7 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float /*scale folded into psi*/, const float *d_psi, unsigned m, unsigned ld,
-                      float *d_phi, int raster, double *d_c, float *kernel_ms, int window, uint64_t *chunks_visited)
+                      float *d_phi, int raster, double *d_c, float *kernel_ms, int window, uint64_t *entries_evaluated)
 {
     const int64_t N = (int64_t)width * height;
     if (pix0 < 0 || pix1 > N || pix0 > pix1 || !valid_ld(ld) || m > ld)
@@ -630,22 +770,22 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
     if (pix0 == pix1) return GLF_OK;
     if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
         switch (ld) {
-        case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
-        case 64: return launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
-        case 128: return launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
-        case 256: return launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        case 64: return launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        case 128: return launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        case 256: return launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
         }
         return GLF_ERR_UNSUPPORTED;
     }
     switch (ld) {
     case 32:
-        return launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        return launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
     case 64:
-        return launch_nystroem<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        return launch_nystroem<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
     case 128:
-        return launch_nystroem<4, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        return launch_nystroem<4, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
     case 256:
-        return launch_nystroem<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, chunks_visited);
+        return launch_nystroem<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
     }
     return GLF_ERR_UNSUPPORTED;
 }

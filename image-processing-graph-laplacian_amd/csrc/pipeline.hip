@@ -402,15 +402,14 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     float *phi_base = phi.p - (size_t)pix0 * ld; // rows addressed by absolute pixel index
     GLF_HIP(ctx, hipMemsetAsync(c.p, 0, sizeof(double) * ld, st));
     float kms = 0.f;
-    uint64_t chunks = 0;
+    uint64_t evaluated = 0;
     GLF_TRY(nystroem_contract(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, (float)(-alpha),
-                              psi.p, m, ld, phi_base, 1, c.p, &kms, opt.skip_exact_zeros, &chunks));
+                              psi.p, m, ld, phi_base, 1, c.p, &kms, opt.skip_exact_zeros, &evaluated));
     S.nystroem_launches = 1;
     S.nystroem_kernel_ms = kms;
     S.contraction = ctx->contraction;
     S.skip_exact_zeros = opt.skip_exact_zeros;
-    // a listed chunk = 64 samples against the workgroup's 256 pixels (ld 256: 128)
-    S.nystroem_evaluated = (double)chunks * 64.0 * (ld == 256 || (ld == 128 && ctx->contraction == GLF_CONTRACT_F16_SPLIT) ? 128.0 : 256.0);
+    S.nystroem_evaluated = (double)evaluated; // kernel entries generated (listed chunks x 64 x workgroup pixels)
     {
         // sample rows of this shard <- Phi_A, and their share of c
         unsigned i0 = 0, i1 = 0;

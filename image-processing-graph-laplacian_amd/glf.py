@@ -21,7 +21,7 @@ import numpy as np
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglf.so")
+LIB_PATH = os.environ.get("GLF_LIBRARY", os.path.join(_HERE, "libglf.so"))  # override: profiling builds only
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "libglf.so not found at %s: build it with `make` (or __graft_entry__.build()); "
