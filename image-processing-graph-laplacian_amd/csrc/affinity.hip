@@ -53,16 +53,18 @@ int build_sample_tables(glf_ctx *ctx, const uint8_t *d_img, int width, int heigh
 // ---- degree: D[i] = sum_pixels K(sample i, pixel) --------------------------------------
 //
 // lane = sample (its row/col/value live in VGPRs); a workgroup (256 samples) sweeps a chunk of 16
-// image rows. The Gaussian is separable in the two coordinates, so per pixel only the photometric
-// part needs an exponential:
-//     K = exp2(-(a_r + s_val dv^2)) * Ec,   a_r = s_loc (r_i - r)^2  (16 registers per chunk),
-//                                           Ec  = exp2(-s_loc (c_i - c)^2)  (once per column, 16 rows)
-// = 4 VALU + 1 v_exp_f32 per entry (7 + 1 without the factorisation). Pixel values are staged as
-// floats in a 16-row LDS tile and read back as wave-wide broadcasts (ds_read_b128 = 4 pixels).
-// VALU/transcendental-bound by design: HBM traffic is ~N bytes per sample block.
-// Accumulation: f32 over one 4-column x 16-row strip (64 terms), f64 across strips, chunks and the
-// final reduction, all in a fixed order => bitwise reproducible, and identical between the dense sweep
-// and the exact-zero-skipping sweep (which visits a 4-column / 16-row aligned sub-range).
+// image rows. The Gaussian is separable in the two coordinates and the photometric part:
+//     K = Er * Ec * P,  Er = exp2(-s_loc (r_i - r)^2)  (16 registers per chunk),
+//                       Ec = exp2(-s_loc (c_i - c)^2)  (once per column, 16 rows),
+//                       P  = exp2(-s_val dv^2)         (per pixel).
+// Two implementations share the sweep: degree_chunk<KY> evaluates P with v_exp_f32 (4 VALU + 1
+// transcendental per entry; used by the full-matrix mode, which also needs sum K y), and
+// degree_chunk_lut gathers P from an LDS table (the D_A path, see below). Pixel values are staged in a
+// 16-row LDS tile and read back as wave-wide broadcasts (ds_read_b128 = 4 pixels). HBM traffic is
+// ~N bytes per sample block: the kernels are bound by the VALU/transcendental pipes or by the LDS.
+// Accumulation: f32 over one 4-column strip, f64 across strips, chunks and the final reduction, all in
+// a fixed order => bitwise reproducible, and identical between the dense sweep and the
+// exact-zero-skipping sweep (which visits a 4-column / 16-row aligned sub-range).
 
 constexpr int DEG_THREADS = 256;
 constexpr int DEG_ROWS = 16;   // rows per chunk (fixed: part of the accumulation order)
@@ -128,18 +130,122 @@ __device__ __forceinline__ double degree_chunk(const uint8_t *__restrict__ img, 
     return total;
 }
 
-__global__ __launch_bounds__(DEG_THREADS) void k_degree(const uint8_t *__restrict__ img, int width, int row0,
-                                                         int row1, const float4 *__restrict__ samples, unsigned p,
-                                                         float s_loc, float s_val, double *__restrict__ partial)
+// ---- the same sweep with the photometric factor from a table (the D_A path) ---------------------
+// K = Er * Ec * P(|v_i - pixel|): the sample value v_i is a u8 fixed per lane and the pixel value is a
+// u8 broadcast to the wave, so P is one of 256 numbers. It is gathered from a copy of the table
+// replicated over the 32 ds_read_b32 banks (lane l reads bank l % 32: conflict-free), addressed by a
+// single v_sad_u32: |128 v_i - 128 pixel| + (table + 4 (l % 32)). Per entry: v_sad_u32 + ds_read_b32 +
+// v_fma_f32 (+ 1/4 ds_read_b128 of four staged pixels, + 1/4 v_fma for the row factor) instead of
+// 4 VALU + v_exp_f32: the kernel moves from the transcendental pipe to the LDS (3 LDS cycles per
+// entry-wave, shared by the CU's 4 SIMDs). Er (16 per chunk) and Ec (4 per strip) still use v_exp_f32;
+// P is correctly rounded from f64 on the host. Same strips, chunks and accumulation order as above.
+// A workgroup is 512 threads: both halves hold the same 256 samples and take 8 of the chunk's 16 rows each
+// (their f64 partial sums are added at the end), so that three workgroups per CU give 6 waves per SIMD to
+// hide the gather latency.
+constexpr int DEGL_SEGW = 256; // 16 KiB tile + 32 KiB table: three workgroups per CU
+constexpr int DEGL_THREADS = 2 * DEG_THREADS;
+constexpr int DEGL_HROWS = DEG_ROWS / 2;
+
+__device__ __forceinline__ unsigned deg_sad_u32(unsigned a, unsigned b, unsigned c)
 {
-    __shared__ __attribute__((aligned(16))) float tile[DEG_ROWS * DEG_SEGW];
-    const unsigned i = blockIdx.x * DEG_THREADS + threadIdx.x;
+    unsigned d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ void degree_lut_init(const float *__restrict__ ptab, float *plut /* [256][32] */)
+{
+    for (int e = threadIdx.x; e < 256 * 32; e += DEGL_THREADS) plut[e] = ptab[e >> 5];
+    // made visible by the first barrier of degree_chunk_lut
+}
+
+__device__ __forceinline__ double degree_chunk_lut(const uint8_t *__restrict__ img, int width, int r_begin, int r_end,
+                                                   int c_begin, int c_end, float4 s, float s_loc,
+                                                   unsigned *tile /* [16][DEGL_SEGW] of 128 * pixel */, const float *plut,
+                                                   double *comb /* [DEG_THREADS] */)
+{
+    const int nr = r_end - r_begin;
+    const int rsel = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / DEG_THREADS)) * DEGL_HROWS; // this half's first row
+    float er[DEGL_HROWS];
+#pragma unroll
+    for (int r = 0; r < DEGL_HROWS; ++r) {
+        const float dr = s.x - (float)(r_begin + rsel + r);
+        er[r] = __builtin_amdgcn_exp2f(-(dr * dr * s_loc));
+    }
+    const unsigned sv128 = 128u * (unsigned)s.z;
+    const unsigned pbase = lds_offset_of(plut) + 4u * (threadIdx.x & 31);
+    double total = 0.0;
+    for (int c0 = c_begin; c0 < c_end; c0 += DEGL_SEGW) {
+        const int seg = min(DEGL_SEGW, c_end - c0);
+        const int seg4 = (seg + 3) & ~3;
+        __syncthreads(); // previous tile fully consumed
+        for (int e = threadIdx.x; e < nr * seg4; e += DEGL_THREADS) {
+            const int r = e / seg4, c = e % seg4;
+            tile[r * DEGL_SEGW + c] = (c < seg) ? 128u * (unsigned)img[(size_t)(r_begin + r) * width + c0 + c] : 0u;
+        }
+        __syncthreads();
+        float dc = s.y - (float)c0; // exact integer, decremented per column
+        for (int c = 0; c < seg4; c += 4) {
+            float ec[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // columns past the end of the range (padding of the last strip) get weight 0
+                ec[u] = (c + u < seg) ? __builtin_amdgcn_exp2f(-(dc * dc * s_loc)) : 0.f;
+                dc -= 1.f;
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < DEGL_HROWS; ++r) {
+                if (rsel + r < nr) { // uniform
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&tile[(rsel + r) * DEGL_SEGW + c]);
+                    float row = ec[0] * lds_f32(deg_sad_u32(sv128, v.x, pbase));
+                    row = fmaf(ec[1], lds_f32(deg_sad_u32(sv128, v.y, pbase)), row);
+                    row = fmaf(ec[2], lds_f32(deg_sad_u32(sv128, v.z, pbase)), row);
+                    row = fmaf(ec[3], lds_f32(deg_sad_u32(sv128, v.w, pbase)), row);
+                    acc = fmaf(er[r], row, acc);
+                }
+            }
+            total += (double)acc;
+        }
+    }
+    // rows 0-7 + rows 8-15, in that order
+    __syncthreads();
+    if (rsel) comb[threadIdx.x - DEG_THREADS] = total;
+    __syncthreads();
+    if (!rsel) total += comb[threadIdx.x];
+    return total; // valid in the first half of the workgroup
+}
+
+struct DegLutLds {
+    unsigned tile[DEG_ROWS * DEGL_SEGW];
+    float plut[256 * 32];
+    double comb[DEG_THREADS];
+};
+
+__global__ __launch_bounds__(DEGL_THREADS) void k_degree(const uint8_t *__restrict__ img, int width, int row0,
+                                                         int row1, const float4 *__restrict__ samples, unsigned p,
+                                                         float s_loc, const float *__restrict__ ptab,
+                                                         double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) DegLutLds sh;
+    degree_lut_init(ptab, sh.plut);
+    const unsigned i = blockIdx.x * DEG_THREADS + threadIdx.x % DEG_THREADS;
     const bool live = i < p;
     const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int r_begin = row0 + (int)blockIdx.y * DEG_ROWS;
     const int r_end = min(r_begin + DEG_ROWS, row1);
-    const double total = degree_chunk<false>(img, width, r_begin, r_end, 0, width, s, s_loc, s_val, tile);
-    if (live) partial[(size_t)blockIdx.y * p + i] = total;
+    const double total = degree_chunk_lut(img, width, r_begin, r_end, 0, width, s, s_loc, sh.tile, sh.plut, sh.comb);
+    if (live && threadIdx.x < DEG_THREADS) partial[(size_t)blockIdx.y * p + i] = total;
+}
+
+// P(e) = exp2(-s_val e^2), e = 0..255, correctly rounded; freed by the caller's DevBuf after its stream sync
+static int upload_photometric_table(glf_ctx *ctx, KernelCoef coef, DevBuf<float> &d_tab, std::vector<float> &h_tab)
+{
+    h_tab.resize(256);
+    for (int e = 0; e < 256; ++e) h_tab[e] = (float)std::exp2(-(double)coef.s_val * e * e);
+    GLF_TRY(d_tab.alloc(ctx, 256));
+    GLF_HIP(ctx, hipMemcpyAsync(d_tab.p, h_tab.data(), sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+    return GLF_OK;
 }
 
 __global__ void k_reduce_partials(const double *__restrict__ partial, unsigned p, int nchunks,
@@ -165,8 +271,11 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
     if (nchunks > 65535) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too tall for one degree launch");
     DevBuf<double> partial;
     GLF_TRY(partial.alloc(ctx, (size_t)nchunks * p));
-    hipLaunchKernelGGL(k_degree, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, ctx->stream, d_img, width, row0, row1,
-                       d_samples, p, coef.s_loc, coef.s_val, partial.p);
+    DevBuf<float> d_ptab;
+    std::vector<float> h_ptab;
+    GLF_TRY(upload_photometric_table(ctx, coef, d_ptab, h_ptab));
+    hipLaunchKernelGGL(k_degree, dim3(nsb, nchunks), dim3(DEGL_THREADS), 0, ctx->stream, d_img, width, row0, row1,
+                       d_samples, p, coef.s_loc, d_ptab.p, partial.p);
     GLF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks,
                        d_degree);
@@ -180,14 +289,15 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
 // block of 256 spatially compact samples only needs the pixels within `radius` of its bounding box; the
 // rest would add +0 (or denormals that cannot change a sum >= 1). Samples are taken in a tile-major
 // order (perm) so that a block is compact in both directions. Same accumulation structure as k_degree.
-__global__ __launch_bounds__(DEG_THREADS) void k_degree_win(const uint8_t *__restrict__ img, int width, int row0, int row1,
+__global__ __launch_bounds__(DEGL_THREADS) void k_degree_win(const uint8_t *__restrict__ img, int width, int row0, int row1,
                                                              const float4 *__restrict__ samples, unsigned p,
                                                              const uint32_t *__restrict__ perm,
                                                              const int4 *__restrict__ blk_box, int radius, float s_loc,
-                                                             float s_val, double *__restrict__ partial)
+                                                             const float *__restrict__ ptab, double *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) float tile[DEG_ROWS * DEG_SEGW];
-    const uint32_t i = perm[blockIdx.x * DEG_THREADS + threadIdx.x]; // 0xFFFFFFFF = padding
+    __shared__ __attribute__((aligned(16))) DegLutLds sh;
+    degree_lut_init(ptab, sh.plut);
+    const uint32_t i = perm[blockIdx.x * DEG_THREADS + threadIdx.x % DEG_THREADS]; // 0xFFFFFFFF = padding
     const bool live = i < p;
     const float4 s = live ? samples[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 box = blk_box[blockIdx.x]; // {rmin, rmax, cmin, cmax} of the block's samples
@@ -198,8 +308,8 @@ __global__ __launch_bounds__(DEG_THREADS) void k_degree_win(const uint8_t *__res
     const int r_begin = rw0 + (int)blockIdx.y * DEG_ROWS;
     const int r_end = min(r_begin + DEG_ROWS, min(rw1 + DEG_ROWS, row1)); // whole chunk, as the dense sweep
     double total = 0.0;
-    if (r_begin < rw1) total = degree_chunk<false>(img, width, r_begin, r_end, cw0, cw1, s, s_loc, s_val, tile); // uniform branch
-    if (live) partial[(size_t)blockIdx.y * p + i] = total;
+    if (r_begin < rw1) total = degree_chunk_lut(img, width, r_begin, r_end, cw0, cw1, s, s_loc, sh.tile, sh.plut, sh.comb); // uniform branch
+    if (live && threadIdx.x < DEG_THREADS) partial[(size_t)blockIdx.y * p + i] = total;
 }
 
 int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
@@ -253,8 +363,11 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
     GLF_TRY(partial.alloc(ctx, (size_t)nchunks * p));
     GLF_HIP(ctx, hipMemcpyAsync(d_perm.p, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice, ctx->stream));
     GLF_HIP(ctx, hipMemcpyAsync(d_box.p, box.data(), sizeof(int4) * box.size(), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_degree_win, dim3(nsb, nchunks), dim3(DEG_THREADS), 0, ctx->stream, d_img, width, row0, row1,
-                       d_samples, p, d_perm.p, d_box.p, radius, coef.s_loc, coef.s_val, partial.p);
+    DevBuf<float> d_ptab;
+    std::vector<float> h_ptab;
+    GLF_TRY(upload_photometric_table(ctx, coef, d_ptab, h_ptab));
+    hipLaunchKernelGGL(k_degree_win, dim3(nsb, nchunks), dim3(DEGL_THREADS), 0, ctx->stream, d_img, width, row0, row1,
+                       d_samples, p, d_perm.p, d_box.p, radius, coef.s_loc, d_ptab.p, partial.p);
     GLF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_reduce_partials, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, partial.p, p, nchunks, d_degree);
     GLF_LAUNCH_CHECK(ctx);
