@@ -206,8 +206,10 @@ def main():
             # every f32-equivalent multiply-add is three f16 MFMA products (hi*hi + hi*lo + lo*hi)
             peak = PEAK_F16_MFMA_TFLOPS / 3.0
             issued = 3.0 * 2.0 * info["nystroem_evaluated"] * ld / (avg_ms * 1e-3) / 1e12
-            kernel = ("k_nystroem_f16s<%d,%d> (Nystroem contraction; K_B generated in registers, both operands split into "
-                      "f16 hi+lo pairs, v_mfma_f32_32x32x16_f16, f32 accumulate)" % (ld // 32, 2 if ld <= 64 else 1))
+            kernel = ("k_nystroem_f16s<%d,%d> (Nystroem contraction; K_B generated in registers%s, both operands split "
+                      "into f16 hi+lo pairs, v_mfma_f32_32x32x16_f16, f32 accumulate)"
+                      % (ld // 32, 2 if ld <= 64 else 1,
+                         " from LDS factor tables" if ld <= 64 and size % 64 == 0 else " with v_exp_f32"))
             basis = "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add"
         else:
             peak, issued = PEAK_F32_MFMA_TFLOPS, achieved

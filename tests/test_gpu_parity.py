@@ -208,6 +208,39 @@ def test_nystroem_permutation_filter(ctx, golden, png, name, m):
     ctx.destroy(L_A, phi_A, Pi, Pi_inv, phi_sf, phi, K_B)
 
 
+@pytest.mark.parametrize("w,h,ns,m", [(128, 96, 150, 8), (192, 64, 300, 40), (64, 200, 90, 64)])
+def test_nystroem_lut_matches_exp_generation(ctx, w, h, ns, m, monkeypatch):
+    """width % 64 == 0 selects the table-driven kernel generation (k_nystroem_f16s<.., LUT>); GLF_NYS_NO_LUT forces
+    the v_exp_f32 variant. Both must match the fp64 oracle, and each other far below that tolerance."""
+    img = glf.synth_image(w, h, seed=5)
+    idx = glf.Sampling(w, h, ns)
+    p = idx.size
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    LA, alpha = orc.laplacian(KA, orc.degree(img, idx))
+    vecs, vals = _lapack_pairs(LA, m)
+    ref = orc.nystroem(img, idx, alpha, vecs, vals).T                     # (N, m) sample-first
+    d_img = ctx.to_device(img)
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    L_A, L_B, _ = ctx.ComputeLaplacianMatrix(None, K_B)
+    phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
+    Pi_inv = ctx.InverseDiagMat(Pi)
+    got = {}
+    for mode in ("lut", "exp"):
+        if mode == "exp":
+            monkeypatch.setenv("GLF_NYS_NO_LUT", "1")
+        else:
+            monkeypatch.delenv("GLF_NYS_NO_LUT", raising=False)
+        phi = ctx.Nystroem(L_B, phi_A, Pi_inv)
+        got[mode] = ctx.mat_to_numpy(phi)
+        ctx.destroy(phi)
+    monkeypatch.delenv("GLF_NYS_NO_LUT", raising=False)
+    scale = np.abs(ref).max()
+    for mode in got:
+        np.testing.assert_allclose(got[mode], ref, rtol=0, atol=2e-4 * scale, err_msg=mode)
+    np.testing.assert_allclose(got["lut"], got["exp"], rtol=0, atol=2e-5 * scale)
+    ctx.destroy(L_A, phi_A, Pi, Pi_inv, K_B)
+
+
 def test_filter_golden_from_python_poc(ctx, golden, png):
     """z_c goldens (PoC stages + LAPACK pairs, tools/gen_golden.py): GPU L_A -> LAPACK
     pairs -> GPU Nystroem/Permutation/filter must land on them."""

@@ -1,0 +1,61 @@
+"""Turn one tools/profile_round.sh output directory into the committed summaries under profiles/.
+
+    python tools/collect_profiles.py gpurun_out/prof_TAG TAG
+
+Writes profiles/TAG_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py), TAG_bench.json /
+TAG_bench_under_rocprof.json (the JSON lines of the two bench runs), TAG_pmc_summary.json (per-kernel
+counter sums of the --pmc passes; one whole-path run each) and updates profiles/r01_pmc_traffic.json, which
+bench.py reads for roofline.traffic. FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as
+MI355X_MICROARCH.md (HBM section) prescribes for gfx950.
+"""
+import csv, glob, json, os, shutil, sys, collections
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+dst = os.path.join(root, "profiles")
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+for name in ("bench_plain", "bench_under_rocprof"):
+    f = os.path.join(src, name + ".json")
+    if os.path.exists(f):
+        line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
+        json.dump(json.loads(line), open(os.path.join(dst, "%s_%s.json" % (tag, name.replace("_plain", ""))), "w"), indent=1)
+
+summary = collections.defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    dur = collections.defaultdict(float)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[r["Kernel_Name"].split("(")[0]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    calls = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            c = r["Counter_Name"]
+            summary[k][c] = summary[k].get(c, 0.0) + float(r["Counter_Value"])
+            calls[k][c] += 1
+    for k in calls:
+        summary[k]["calls"] = max(calls[k].values())
+        summary[k]["total_ms_pass_" + os.path.basename(d)[4:]] = round(dur.get(k, 0.0), 3)
+json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+
+nys = [k for k in summary if "k_nystroem_f16s" in k and "FETCH_SIZE" in summary[k]]
+if nys:
+    k = max(nys, key=lambda k: summary[k]["FETCH_SIZE"])
+    fetch = summary[k]["FETCH_SIZE"] / summary[k]["calls"] * 1024.0 * 2.0
+    write = summary[k]["WRITE_SIZE"] / summary[k]["calls"] * 1024.0
+    tf = os.path.join(dst, "r01_pmc_traffic.json")
+    traffic = json.load(open(tf)) if os.path.exists(tf) else {}
+    traffic["4096x4096_m64_f16s_gpus1"] = {
+        "nystroem_bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write,
+        "kernel": k,
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/%s_pmc_summary.json); FETCH_SIZE "
+                  "doubled per MI355X_MICROARCH.md (gfx950 counts 16-B/lane reads at half)" % tag}
+    json.dump(traffic, open(tf, "w"), indent=1)
+    print("nystroem traffic per launch: %.2f GB fetch (x2) + %.2f GB write" % (fetch / 1e9, write / 1e9))
+for k in sorted(summary, key=lambda k: -summary[k].get("GRBM_GUI_ACTIVE", 0))[:6]:
+    print(k[:70], {c: v for c, v in summary[k].items() if c in ("FETCH_SIZE", "WRITE_SIZE", "calls")})

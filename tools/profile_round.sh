@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): bench.py under rocprofv3 --stats, then the HBM-traffic PMC passes.
+# usage: tools/profile_round.sh TAG      -> gpurun_out/prof_TAG/...
+set -e
+tag=${1:-r01}
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
+python3 bench.py --steps 3 --warmup 1 > $out/bench_plain.json 2> $out/bench_plain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/stats.err
+for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 tools/run_once.py 4096 0.005 64 0 1 > $out/pmc_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_SQ -- python3 tools/run_once.py 4096 0.005 64 0 1 > $out/pmc_SQ.log 2>&1
+echo profile_round done
