@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace glf {
 
@@ -855,9 +856,200 @@ __global__ void k_scale_all(float *__restrict__ X, unsigned n, unsigned ld, unsi
     if (nr != 0.0) X[e] = (float)((double)X[e] / nr);
 }
 
+
+// ---- Gram-matrix form of the same classical Gram-Schmidt -------------------------------------------------
+// The projections <v_k,u_j>/<u_j,u_j> of classical GS are determined by the Gram matrix G = V^T V alone:
+//   <v_k,u_j> = G_kj - sum_{i<j} c_ij <v_k,u_i>,   c_jk = <v_k,u_j> / q_j,   q_k = <u_k,u_k> = G_kk - sum_j c_jk <v_k,u_j>
+// (the LDL^T recurrence of G), and U = V C^-1 with C unit upper triangular. So one pass over the vectors builds G in
+// f64 (exact products of f32 entries, f64 accumulation in fixed order), one workgroup runs the m-step recurrence and
+// inverts C in f64, and one more pass applies X <- X (C^-1 diag(1/|u_k|)): 4 launches instead of 3 m, same result
+// as the column-by-column sweep up to rounding (the sweep rounds every u_k to f32 before it is used; here the
+// coefficients are f64 throughout). The recurrence loses digits as cond(V)^2 eps_f64: if any q_k falls below
+// GSF_COND_FLOOR * G_kk (vectors dependent to ~5 digits) the device raises a flag, X is left untouched and the
+// caller runs the column-by-column sweep instead.
+constexpr int GSF_ROWS = 512;            // rows per Gram workgroup
+constexpr double GSF_COND_FLOOR = 1e-10; // q_k / G_kk below this: fall back to the sequential sweep
+
+// Gpart[chunk][a][b] = sum_{i in chunk} X[i][a] X[i][b] for the tiles on and above the diagonal; 16 x 16 threads, each an
+// E x E sub-block of a TILE x TILE tile.
+template <int TILE>
+__global__ __launch_bounds__(256) void k_gsf_gram(const float *__restrict__ X, unsigned n, unsigned ld,
+                                                   double *__restrict__ Gpart)
+{
+    constexpr int E = TILE / 16;
+    const int mb = ld / TILE;
+    const int ta = blockIdx.y / mb, tb = blockIdx.y % mb;
+    if (tb < ta) return;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    double acc[E][E];
+#pragma unroll
+    for (int u = 0; u < E; ++u)
+#pragma unroll
+        for (int v = 0; v < E; ++v) acc[u][v] = 0.0;
+    const unsigned r0 = blockIdx.x * GSF_ROWS, r1 = min(r0 + GSF_ROWS, n);
+    const int ca = ta * TILE + E * ty, cb = tb * TILE + E * tx;
+#pragma unroll 4
+    for (unsigned i = r0; i < r1; ++i) {
+        const float *row = X + (size_t)i * ld;
+        float a[E], b[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            a[u] = row[ca + u];
+            b[u] = row[cb + u];
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u)
+#pragma unroll
+            for (int v = 0; v < E; ++v) acc[u][v] = fma((double)a[u], (double)b[v], acc[u][v]);
+    }
+    double *out = Gpart + (size_t)blockIdx.x * ld * ld;
+#pragma unroll
+    for (int u = 0; u < E; ++u)
+#pragma unroll
+        for (int v = 0; v < E; ++v) out[(size_t)(ca + u) * ld + cb + v] = acc[u][v];
+}
+
+// G = sum over chunks (fixed order), mirrored into the tiles below the diagonal
+__global__ __launch_bounds__(256) void k_gsf_sum(const double *__restrict__ Gpart, int nchunks, unsigned ld, int tile,
+                                                  double *__restrict__ G)
+{
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ld * ld) return;
+    const unsigned a = e / ld, b = e % ld;
+    if (b / tile < a / tile) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += Gpart[(size_t)c * ld * ld + e];
+    G[e] = s;
+    if (b / tile > a / tile) G[(size_t)b * ld + a] = s;
+}
+
+// One workgroup. S (ld x ld, f64, LDS for ld <= 64, else global) starts as G and is reduced in place:
+// upper part S[j][k] <- c_jk, diagonal <- q_j, then the strictly lower part S[k][j] <- T[j][k], T = C^-1.
+// Outputs: Tn[j][k] = T[j][k] / |u_k| (upper triangular, zero elsewhere), norms[k] = |u_k| = sqrt(q_k), flag.
+__device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double *__restrict__ G, double *__restrict__ Tn,
+                               double *__restrict__ norms, int *__restrict__ flag)
+{
+    const unsigned t = threadIdx.x;
+    __shared__ int bad;
+    if (t == 0) bad = 0;
+    for (unsigned e = t; e < ld * ld; e += 256) S[e] = G[e];
+    __syncthreads();
+    for (unsigned j = 0; j < m; ++j) {
+        const double qj = S[(size_t)j * ld + j];
+        if (t == 0 && !(qj > GSF_COND_FLOOR * G[(size_t)j * ld + j]) && G[(size_t)j * ld + j] > 0.0) bad = 1;
+        // c_jk for k > j (0 for a zero vector, as the sweep does)
+        for (unsigned k = j + 1 + t; k < m; k += 256) S[(size_t)j * ld + k] = qj != 0.0 ? S[(size_t)k * ld + j] / qj : 0.0;
+        __syncthreads();
+        // Schur complement: S[k][l] -= c_jk <v_l,u_j>, k, l > j  (<v_l,u_j> = S[l][j], still untouched)
+        const unsigned w = m - j - 1;
+        for (unsigned e = t; e < w * w; e += 256) {
+            const unsigned k = j + 1 + e / w, l = j + 1 + e % w;
+            S[(size_t)k * ld + l] -= S[(size_t)j * ld + k] * S[(size_t)l * ld + j];
+        }
+        __syncthreads(); // (column j below the diagonal is read above and only overwritten by the inversion below)
+    }
+    // T = C^-1, column k by thread k: T[k][k] = 1, T[j][k] = -sum_{i=j+1..k} c_ji T[i][k]; stored at S[k][j] (j < k)
+    for (unsigned k = t; k < m; k += 256) {
+        for (int j = (int)k - 1; j >= 0; --j) {
+            double acc = S[(size_t)j * ld + k]; // i = k term: c_jk * 1
+            for (unsigned i = (unsigned)j + 1; i < k; ++i) acc = fma(S[(size_t)j * ld + i], S[(size_t)k * ld + i], acc);
+            S[(size_t)k * ld + j] = -acc;
+        }
+    }
+    __syncthreads();
+    for (unsigned e = t; e < ld * ld; e += 256) {
+        const unsigned j = e / ld, k = e % ld;
+        double v = 0.0;
+        if (k < m && j <= k) {
+            const double qk = S[(size_t)k * ld + k];
+            const double nk = qk > 0.0 ? sqrt(qk) : 0.0;
+            v = (j == k ? 1.0 : S[(size_t)k * ld + j]) * (nk != 0.0 ? 1.0 / nk : 1.0); // zero norm: left unscaled
+        }
+        Tn[e] = v;
+    }
+    if (t < m) {
+        const double qk = S[(size_t)t * ld + t];
+        norms[t] = qk > 0.0 ? sqrt(qk) : 0.0;
+    }
+    if (t == 0) *flag = bad;
+}
+
+__global__ __launch_bounds__(256) void k_gsf_recur_lds(unsigned ld, unsigned m, const double *__restrict__ G,
+                                                        double *__restrict__ Tn, double *__restrict__ norms,
+                                                        int *__restrict__ flag)
+{
+    __shared__ double S[64 * 64];
+    gsf_recur_body(S, ld, m, G, Tn, norms, flag);
+}
+
+__global__ __launch_bounds__(256) void k_gsf_recur_global(unsigned ld, unsigned m, const double *__restrict__ G,
+                                                           double *S, double *__restrict__ Tn, double *__restrict__ norms,
+                                                           int *__restrict__ flag)
+{
+    gsf_recur_body(S, ld, m, G, Tn, norms, flag);
+}
+
+// X[i][k] <- sum_{j<=k} X[i][j] Tn[j][k] (f64 accumulation), in place; 8192 / ld rows per workgroup, thread = column.
+__global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned m,
+                                                    const double *__restrict__ Tn, const int *__restrict__ flag)
+{
+    if (*flag) return; // ill-conditioned: the caller runs the sequential sweep on the untouched X
+    __shared__ float xs[8192];
+    __shared__ double ts[4096];
+    const unsigned rows = 8192 / ld, jb = min(4096u / ld, ld); // rows per workgroup; T rows per staged block (Tn has ld rows)
+    const unsigned r0 = blockIdx.x * rows;
+    const unsigned col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld, rpt = rows / nrl; // rpt = 32
+    for (unsigned e = threadIdx.x; e < rows * ld; e += 256) {
+        const unsigned i = r0 + e / ld;
+        xs[e] = i < n ? X[(size_t)i * ld + e % ld] : 0.f;
+    }
+    double acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc[q] = 0.0;
+    for (unsigned j0 = 0; j0 < m; j0 += jb) {
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < jb * ld; e += 256) ts[e] = Tn[(size_t)j0 * ld + e];
+        __syncthreads();
+        const unsigned jn = min(jb, m - j0);
+        for (unsigned j = 0; j < jn; ++j) {
+            const double tv = ts[j * ld + col];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc[q] = fma((double)xs[(rl + q * nrl) * ld + j0 + j], tv, acc[q]);
+        }
+    }
+    (void)rpt;
+    if (col < m)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const unsigned i = r0 + rl + q * nrl;
+            if (i < n) X[(size_t)i * ld + col] = (float)acc[q];
+        }
+}
+
+struct GsFusedWork {
+    DevBuf<double> Gpart, G, S, Tn;
+    DevBuf<int> flag;
+    int nchunks = 0;
+    unsigned n = 0, ld = 0;
+    int init(glf_ctx *ctx, unsigned n_, unsigned ld_)
+    {
+        if (n == n_ && ld == ld_) return GLF_OK;
+        n = n_;
+        ld = ld_;
+        nchunks = (int)ceil_div(n, GSF_ROWS);
+        GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
+        GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
+        GLF_TRY(Tn.alloc(ctx, (size_t)ld * ld));
+        if (ld > 64) GLF_TRY(S.alloc(ctx, (size_t)ld * ld));
+        GLF_TRY(flag.alloc(ctx, 1));
+        return GLF_OK;
+    }
+};
+
 struct GsWork {
     DevBuf<double> partial, norms, q, normpart;
     DevBuf<float> coef;
+    GsFusedWork fused;
     int nblk = 0;
     int init(glf_ctx *ctx, unsigned n, unsigned ld)
     {
@@ -875,7 +1067,32 @@ struct GsWork {
     }
 };
 
-static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld)
+// returns GLF_OK with *fell_back = 1 when the device found V too ill-conditioned (X untouched)
+static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, unsigned n, unsigned m, unsigned ld,
+                                    double *d_norms, int *fell_back)
+{
+    hipStream_t st = ctx->stream;
+    GLF_TRY(f.init(ctx, n, ld));
+    const int tile = ld >= 64 ? 64 : 32, mb = (int)ld / tile;
+    if (tile == 64)
+        hipLaunchKernelGGL((k_gsf_gram<64>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
+    else
+        hipLaunchKernelGGL((k_gsf_gram<32>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
+    hipLaunchKernelGGL(k_gsf_sum, dim3((ld * ld + 255) / 256), dim3(256), 0, st, f.Gpart.p, f.nchunks, ld, tile, f.G.p);
+    if (ld <= 64)
+        hipLaunchKernelGGL(k_gsf_recur_lds, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.Tn.p, d_norms, f.flag.p);
+    else
+        hipLaunchKernelGGL(k_gsf_recur_global, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.S.p, f.Tn.p, d_norms, f.flag.p);
+    hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, 8192 / ld)), dim3(256), 0, st, X, n, ld, m, f.Tn.p, f.flag.p);
+    GLF_LAUNCH_CHECK(ctx);
+    int h_flag = 0;
+    GLF_HIP(ctx, hipMemcpyAsync(&h_flag, f.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    *fell_back = h_flag;
+    return GLF_OK;
+}
+
+static int orthonormalise_seq_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld)
 {
     hipStream_t st = ctx->stream;
     for (unsigned k = 0; k < m; ++k) {
@@ -891,6 +1108,20 @@ static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, uns
     hipLaunchKernelGGL(k_scale_all, dim3((unsigned)ceil_div((int64_t)n * ld, 256)), dim3(256), 0, st, X, n, ld, m, w.norms.p);
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
+}
+
+// OrthonormaliseVecs (hpc/gram_schmidt.c:29-64): the Gram-matrix form unless GLF_GS=seq or the vectors are too
+// ill-conditioned for it. Either way w.norms holds the post-GS norms |u_k|.
+static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld)
+{
+    const char *mode = std::getenv("GLF_GS");
+    if (!(mode && std::strcmp(mode, "seq") == 0)) {
+        int fell_back = 0;
+        GLF_TRY(orthonormalise_fused_dev(ctx, w.fused, X, n, m, ld, w.norms.p, &fell_back));
+        if (!fell_back) return GLF_OK;
+        if (std::getenv("GLF_VERBOSE")) fprintf(stderr, "[glf] Gram-Schmidt: ill-conditioned block, column-by-column sweep\n");
+    }
+    return orthonormalise_seq_dev(ctx, w, X, n, m, ld);
 }
 
 int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *h_norms)
