@@ -189,7 +189,7 @@ static png_bytep *EntireComputation(png_bytep *img_bytes, unsigned width, unsign
     if (glf_memcpy_h2d(ctx, d_img, flat, n) != GLF_OK) goto out;
     const double t = wtime();
     printf("Computing entire affinity matrix, Laplacian matrix and output image (matrices not stored)... ");
-    const int rc = glf_EntireComputation(ctx, (const uint8_t *)d_img, (int)width, (int)height, GLF_KERNEL_BILATERAL, 40.0f, 30.0f,
+    const int rc = glf_EntireComputation(ctx, (const uint8_t *)d_img, (int)width, (int)height, GLF_KERNEL_BILATERAL, stage_h_loc, stage_h_val,
                                          (uint8_t *)d_out, NULL, NULL);
     if (rc != GLF_OK) {
         fprintf(stderr, "\nglf_EntireComputation: %s (%s)\n", glf_strerror(rc), glf_ctx_last_error(ctx));
@@ -221,6 +221,9 @@ static png_bytep *FusedComputation(png_bytep *img_bytes, unsigned width, unsigne
     opt.num_eigvals = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
     opt.opti_gs = GetOptiGramSchmidt();
     opt.epsilon = GetInverseIterationEpsilon();
+    opt.h_loc = stage_h_loc;
+    opt.h_val = stage_h_val;
+    opt.gain = stage_gain;
     const size_t n = (size_t)width * height;
     void *d_img = NULL, *d_out = NULL;
     uint8_t *flat = (uint8_t *)malloc(n);
@@ -263,6 +266,12 @@ int main(int argc, char **argv)
     if (InitProgram(dev ? atoi(dev) : 0) != GLF_OK) return 2; /* :284 */
     const double start_time = wtime();
     printf("Running with %d processes\n", 1); /* :286 */
+    { /* additions: the reference's constants as flags, same defaults */
+        const char *v;
+        if ((v = opt_value("-h_loc")) && atof(v) > 0.0) stage_h_loc = (float)atof(v);
+        if ((v = opt_value("-h_val")) && atof(v) > 0.0) stage_h_val = (float)atof(v);
+        if ((v = opt_value("-gain"))) stage_gain = (float)atof(v);
+    }
     GetFilePath(filename, sizeof(filename));
 
     int width = 0, height = 0;

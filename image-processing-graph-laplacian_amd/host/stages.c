@@ -9,6 +9,8 @@
 #include <string.h>
 
 static glf_ctx *g_world = NULL;
+/* the reference's compile-time constants, adjustable from the command line (-h_loc, -h_val, -gain) */
+float stage_h_loc = 40.0f, stage_h_val = 30.0f, stage_gain = 3.0f;
 static glf_eig_stats g_eig_stats;
 static uint8_t *g_dimg = NULL; /* device copy of the image, uploaded once per run */
 static size_t g_dimg_bytes = 0;
@@ -91,9 +93,9 @@ int ComputeAffinityMatrices(Mat *K_A, Mat *K_B, const png_bytep *img_bytes, int 
     if (!d_img) return GLF_ERR_NOMEM;
     *K_A = new_mat();
     *K_B = new_mat();
-    /* bilateral, h_loc = 40, h_val = 30: hpc/affinity.c:117-121 */
+    /* bilateral, h_loc = 40, h_val = 30: hpc/affinity.c:117-121 (stage_h_loc / stage_h_val default to those) */
     return glf_ComputeAffinityMatrices(g_world, *K_A, *K_B, d_img, width, height, sample_size, sample_indices,
-                                       GLF_KERNEL_BILATERAL, 40.0f, 30.0f);
+                                       GLF_KERNEL_BILATERAL, stage_h_loc, stage_h_val);
 }
 
 int ComputeLaplacianMatrix(Mat *L_A, Mat *L_B, Mat K_A, Mat K_B)
@@ -160,8 +162,8 @@ png_bytep *ComputeResultFromLaplacian(const png_bytep *img_bytes, Mat phi, Mat P
     void *d_out = NULL;
     if (!d_img || glf_malloc(g_world, &d_out, n) != GLF_OK) return NULL;
     png_bytep *rows = NULL;
-    /* gain 3.0: hpc/display.c:73 */
-    if (glf_ComputeResultFromLaplacian(g_world, d_img, phi, Pi, width, height, 3.0f, (uint8_t *)d_out, NULL) == GLF_OK) {
+    /* gain 3.0: hpc/display.c:73 (stage_gain defaults to it) */
+    if (glf_ComputeResultFromLaplacian(g_world, d_img, phi, Pi, width, height, stage_gain, (uint8_t *)d_out, NULL) == GLF_OK) {
         uint8_t *flat = (uint8_t *)malloc(n);
         if (flat && glf_memcpy_d2h(g_world, flat, d_out, n) == GLF_OK) {
             rows = (png_bytep *)malloc(sizeof(png_bytep) * height); /* OneColMat2pngbytes, hpc/utils.c:509-513 */

@@ -15,6 +15,9 @@ typedef png_byte *png_bytep;
 typedef glf_mat *Mat;             /* replaces PETSc Mat (MATMPIDENSE / diagonal MATMPIAIJ) */
 
 glf_ctx *glf_world(void);         /* replaces PETSC_COMM_WORLD */
+/* hpc/affinity.c:117-118 and hpc/display.c:73 hard-code 40, 30 and 3.0; these default to the same values */
+extern float stage_h_loc, stage_h_val, stage_gain;
+
 int InitProgram(int device);      /* hpc/image_processing.c:30-38 */
 void FinalizeProgram(void);       /* SlepcFinalize, hpc/image_processing.c:332 */
 void MatDestroy(Mat *m);

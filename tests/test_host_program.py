@@ -89,3 +89,21 @@ def test_default_num_eigvals_and_flag_fallbacks(tmp_path, png):
     assert np.mean(exact != exact_ref) < 2e-3 and np.abs(exact.astype(int) - exact_ref.astype(int)).max() <= 1
     r3 = _run(["-f", str(tmp_path / "nope.png")], str(tmp_path))
     assert r3.returncode == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-fused"]])
+def test_constants_as_flags(tmp_path, png, extra):
+    """-gain / -h_loc / -h_val expose hpc/display.c:73 and hpc/affinity.c:117-118 (defaults = the reference's
+    constants). gain 0 => z = min(255, y + 0): the output is the input; other widths match the oracle."""
+    img = png("test.png")
+    r = _run(["-f", TEST_PNG, "-num_eigvals", "8", "-gain", "0"] + extra, str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()
+    np.testing.assert_array_equal(glf.read_png(str(tmp_path / "results" / "output.png")), img)
+    r = _run(["-f", TEST_PNG, "-num_eigvals", "8", "-h_loc", "25", "-h_val", "45", "-gain", "2"] + extra, str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()
+    out = glf.read_png(str(tmp_path / "results" / "output.png"))
+    prm = orc.default_params()
+    prm.h_loc, prm.h_val = 25.0, 45.0
+    _, out_ref, _ = orc.image_processing(img, 100, 8, epsilon=0.1, inner_rtol=1e-5, seed=1, gain=2.0, prm=prm)
+    assert psnr(out, out_ref) >= 50.0
