@@ -14,7 +14,10 @@
 // VALU/transcendental-bound (kernel generation) below.
 #include "glf_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <vector>
 
 namespace glf {
 
@@ -587,7 +590,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8
             }
             // The two waves of a SIMD drift into lockstep (both generating, then both contracting) unless the
             // one in its MFMA burst wins the issue arbitration: the other then fills the gaps with its VALU.
+#ifndef NYS_DBG_NO_SETPRIO
             __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int j = 0; j < MB; ++j) {
                 const f16x8 bh = sfrag[((t * MB + j) * 2 + 0) * 64 + lane];
@@ -603,7 +608,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8
 #endif
                 }
             }
+#ifndef NYS_DBG_NO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
+#endif
         }
         lds_dma_drain(); // this wave's pieces of the next chunk have landed ...
         __syncthreads(); // ... and so have everybody else's; buffer `buf` is free again
@@ -758,6 +765,8 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     return GLF_OK;
 }
 
+#include "nystroem_grid.inc"
+
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float /*scale folded into psi*/, const float *d_psi, unsigned m, unsigned ld,
@@ -768,6 +777,12 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
         return set_error(ctx, GLF_ERR_INVALID, "nystroem_contract: bad range or ld=%u", ld);
     if (kernel_ms) *kernel_ms = 0.f;
     if (pix0 == pix1) return GLF_OK;
+    {
+        // a tensor-grid sample set (hpc/sampling.c always yields one) takes the factored contraction
+        const int rc = nystroem_contract_grid(ctx, d_img, width, height, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, ld,
+                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, nullptr);
+        if (rc != GLF_ERR_UNSUPPORTED) return rc;
+    }
     if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
         switch (ld) {
         case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
