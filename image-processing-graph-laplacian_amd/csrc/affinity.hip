@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace glf {
 
@@ -373,6 +374,22 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream)); // host vectors and DevBufs are released at scope exit
     return GLF_OK;
+}
+
+#include "grid_common.inc"
+#include "affinity_grid.inc"
+
+// D_A over the image rows [row0, row1): the grid-factored form when the samples are a tensor grid, else the
+// direct sweep (windowed when exact zeros may be skipped). *evaluated = kernel entries represented.
+int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
+                     unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated)
+{
+    const int rc = degree_rows_grid(ctx, d_img, width, height, row0, row1, d_samples, p, h_idx, coef, d_degree, window, evaluated);
+    if (rc != GLF_ERR_UNSUPPORTED) return rc;
+    if (window && coef.s_loc > 0.f)
+        return degree_rows_windowed(ctx, d_img, width, height, row0, row1, d_samples, p, h_idx, coef, d_degree, evaluated);
+    if (evaluated) *evaluated = (double)p * (double)(row1 - row0) * (double)width;
+    return degree_rows(ctx, d_img, width, height, row0, row1, d_samples, p, coef, d_degree);
 }
 
 // ---- full-matrix mode (-no_approx): z = clamp(y - L y), L = alpha (D - K) over ALL pixels ---------------

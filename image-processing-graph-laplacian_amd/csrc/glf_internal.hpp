@@ -187,6 +187,8 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
 
 // Same sums, skipping pixels whose kernel entry underflows to exactly 0 in f32 for every sample of a block
 // (h_idx: host sample indices, needed for the tile-major sample order). evaluated: entries executed.
+int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
+                     unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated);
 int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
                          const float4 *d_samples, unsigned p, const unsigned *h_idx, KernelCoef coef,
                          double *d_degree, double *evaluated);

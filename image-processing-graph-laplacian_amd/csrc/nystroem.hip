@@ -765,6 +765,7 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     return GLF_OK;
 }
 
+#include "grid_common.inc"
 #include "nystroem_grid.inc"
 
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,

@@ -79,7 +79,7 @@ int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const 
     GLF_TRY(deg.alloc(ctx, p));
     int row0, row1;
     shard_rows(ctx, height, &row0, &row1);
-    GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
+    GLF_TRY(degree_rows_auto(ctx, d_img, width, height, row0, row1, tb.samples.p, p, sample_indices, coef, deg.p, 0, nullptr));
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     if (K_A) {
         const int64_t lda = round_up(p, VEC_PAD);
@@ -319,13 +319,8 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     GLF_TRY(build_sample_tables(ctx, d_img, width, height, p, h_idx, tb));
     DevBuf<double> deg;
     GLF_TRY(deg.alloc(ctx, p));
-    if (opt.skip_exact_zeros && coef.s_loc > 0.f) {
-        GLF_TRY(degree_rows_windowed(ctx, d_img, width, height, row0, row1, tb.samples.p, p, h_idx, coef, deg.p,
-                                     &S.degree_evaluated));
-    } else {
-        GLF_TRY(degree_rows(ctx, d_img, width, height, row0, row1, tb.samples.p, p, coef, deg.p));
-        S.degree_evaluated = (double)p * (double)(pix1 - pix0);
-    }
+    GLF_TRY(degree_rows_auto(ctx, d_img, width, height, row0, row1, tb.samples.p, p, h_idx, coef, deg.p, opt.skip_exact_zeros,
+                             &S.degree_evaluated));
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     // ---- Laplacian ---------------------------------------------------------------------------

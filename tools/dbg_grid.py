@@ -2,7 +2,7 @@ import sys, time, os
 sys.path.insert(0, "image-processing-graph-laplacian_amd"); sys.path.insert(0, "oracle")
 import numpy as np, torch, glf
 ctx = glf.Context(0)
-cases = [(1280, 1024, 0.005, 32), (2048, 2048, 0.005, 64), (4096, 4096, 0.005, 64)]
+cases = [(96, 64, 0.02, 8), (450, 300, 0.01, 40), (1280, 1024, 0.005, 32), (4096, 4096, 0.005, 64)]
 if len(sys.argv) > 1: cases = cases[:int(sys.argv[1])]
 for (W, H, frac, m) in cases:
     img = glf.synth_image(W, H, seed=7)
@@ -12,13 +12,13 @@ for (W, H, frac, m) in cases:
         opt.skip_exact_zeros = skip
         outs = {}
         for mode in ("grid", "direct"):
-            if mode == "direct": os.environ["GLF_NYS_NO_GRID"] = "1"
-            else: os.environ.pop("GLF_NYS_NO_GRID", None)
+            if mode == "direct": os.environ["GLF_NYS_NO_GRID"] = "1"; os.environ["GLF_DEG_NO_GRID"] = "1"
+            else: os.environ.pop("GLF_NYS_NO_GRID", None); os.environ.pop("GLF_DEG_NO_GRID", None)
             ctx.image_processing(d_img, opt)
             out, zf, info = ctx.image_processing(d_img, opt, want_float=True)
             outs[mode] = (out.cpu().numpy(), zf.cpu().numpy(), info)
             print(W, H, "skip", skip, mode, "total %.1f ms" % info["ms_total"], "nys %.1f" % info["ms_nystroem"], "kernel %.1f" % info["nystroem_kernel_ms"],
-                  "eval %.3g" % info["nystroem_evaluated"], flush=True)
+                  "eval %.3g" % info["nystroem_evaluated"], "aff %.1f alpha %.12g deval %.3g" % (info["ms_affinity"], info["alpha"], info["degree_evaluated"]), flush=True)
         a, b = outs["grid"], outs["direct"]
         print("  out diff px:", int((a[0] != b[0]).sum()), "max|dz|: %.3g" % float(np.abs(a[1]-b[1]).max()), "rel l2: %.3g" % float(np.linalg.norm(a[1]-b[1])/np.linalg.norm(b[1])), flush=True)
         if skip == 0: dense = a[1].copy()
