@@ -167,10 +167,14 @@ def main():
         barrier()
         t0 = time.perf_counter()
         kernel_ms = []
+        mv = {"launches": 0, "ms": 0.0, "bytes": 0.0}
         stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
         for _ in range(args.steps):
             _, _, info = ctx.image_processing(d_img, opt, out=d_out)
             kernel_ms.append(info["nystroem_kernel_ms"])
+            mv["launches"] += info["matvecs"]
+            mv["ms"] += info["matvec_ms"]
+            mv["bytes"] += info["matvec_bytes"]
             for k in stage_ms:
                 stage_ms[k] += info[k]
         barrier()
@@ -179,6 +183,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        info["mv"] = mv
         return elapsed / args.steps, info, float(np.mean(kernel_ms)), {k[3:]: round(v / args.steps, 3) for k, v in stage_ms.items()}
 
     sec_per_step, info, avg_ms, stage_ms = run_leg(opt)
@@ -202,24 +207,42 @@ def main():
         ld = 32
         while ld < m:
             ld *= 2
+        grid_path = info["nystroem_path"] == 1
+        issued = info["nystroem_mfma_flops"] / (avg_ms * 1e-3) / 1e12
         if info["contraction"] == glf.CONTRACT_F16_SPLIT:
             # every f32-equivalent multiply-add is three f16 MFMA products (hi*hi + hi*lo + lo*hi)
-            peak = PEAK_F16_MFMA_TFLOPS / 3.0
-            issued = 3.0 * 2.0 * info["nystroem_evaluated"] * ld / (avg_ms * 1e-3) / 1e12
-            kernel = ("k_nystroem_f16s<%d,%d> (Nystroem contraction; K_B generated in registers%s, both operands split "
-                      "into f16 hi+lo pairs, v_mfma_f32_32x32x16_f16, f32 accumulate)"
-                      % (ld // 32, 2 if ld <= 64 else 1,
-                         " from LDS factor tables" if ld <= 64 and size % 64 == 0 else " with v_exp_f32"))
-            basis = "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add"
+            nys_peak = PEAK_F16_MFMA_TFLOPS
+            if grid_path:
+                nys_kernel = ("k_grid_rowpass<%d> + k_grid_colpass<%d> (grid-factored Nystroem contraction: "
+                              "T[r][v][b] = sum_a P Er Psi on v_mfma_f32_32x32x16_f16 with both operands split into f16 hi+lo "
+                              "pairs, then Phi = sum_b Ec T in f32 FMAs)" % (ld // 32, ld // 32))
+            else:
+                nys_kernel = ("k_nystroem_f16s<%d,%d> (direct Nystroem contraction; K_B generated in registers%s, split-f16 MFMA)"
+                              % (ld // 32, 2 if ld <= 64 else 1,
+                                 " from LDS factor tables" if ld <= 64 and size % 64 == 0 else " with v_exp_f32"))
         else:
-            peak, issued = PEAK_F32_MFMA_TFLOPS, achieved
-            kernel = "k_nystroem<%d,%d> (Nystroem contraction, v_mfma_f32_32x32x2_f32, K_B generated in registers)" % (ld // 32, 2 if ld <= 128 else 1)
-            basis = "f32 dense matrix peak"
+            nys_peak = PEAK_F32_MFMA_TFLOPS
+            nys_kernel = "k_nystroem<%d,%d> (direct Nystroem contraction, v_mfma_f32_32x32x2_f32)" % (ld // 32, 2 if ld <= 128 else 1)
+        nystroem = {
+            "kernel": nys_kernel, "path": "grid-factored" if grid_path else "direct",
+            "avg_ms_per_step": round(avg_ms, 3), "launches_per_step": info["nystroem_launches"],
+            "algorithmic_flops": flops, "algorithmic_tflops": round(achieved, 1),
+            "mfma_issued_tflops": round(issued, 1), "mfma_peak_tflops": nys_peak,
+            "mfma_issued_frac_of_peak": round(issued / nys_peak, 4),
+            "note": "algorithmic = SURVEY 8d W_nys = 2 (N-p) p m flop of the direct contraction; the grid-factored form "
+                    "computes the same sums with 2 H 256 nc nr m + 2 N nc m flop, so algorithmic_tflops may exceed the MFMA "
+                    "peak; mfma_issued counts the f16 MFMA flops actually executed (x3 for the split products)",
+        }
+        # dominant kernel of the step: the L_A sweep of the eigensolver (k_block_matvec_f16s), HBM-bound
+        mvs = info["mv"]
+        mv_avg_ms = mvs["ms"] / max(1, mvs["launches"])
+        mv_bytes = mvs["bytes"] / max(1, mvs["launches"])          # algorithmic: 4 p (rows of this rank) per launch
+        mv_gbs = mv_bytes / (mv_avg_ms * 1e-3) / 1e9 if mv_avg_ms > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this configuration
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             key = "%dx%d_m%d_%s_gpus%d" % (size, size, m, "f16s" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32", n_gpus)
-            traffic = prof.get(key, {}).get("nystroem_bytes_per_launch")
+            traffic = prof.get(key, {}).get("matvec_bytes_per_launch")
         except (OSError, ValueError):
             pass
         line = {
@@ -234,11 +257,15 @@ def main():
                        "contraction": "f16 split (hi+lo), f32 accumulate" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32 MFMA",
                        "sharding": "pixel rows / %d ranks; L_A column blocks / %d ranks" % (n_gpus, n_gpus)},
             "stage_ms_rank0": stage_ms,
-            "roofline": {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1),
-                         "peak_basis": basis, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "avg_launch_ms": round(avg_ms, 3), "flops_per_launch": flops,
-                         "mfma_issued_tflops": round(issued, 1),
-                         "note": "achieved = algorithmic 2 (N-p) p m flop / mean HIP-event duration of the launch"},
+            "roofline": {"kernel": "k_block_matvec_f16s<%d> (block mat-vec of the PCG / residual: L_A streamed once per launch, "
+                                   "split-f16 MFMA contraction with the %d-column block)" % (ld // 32, ld),
+                         "bound": "hbm", "achieved": round(mv_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(mv_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(mv_avg_ms, 4), "launches_per_step": mvs["launches"] / args.steps,
+                         "bytes_per_launch": mv_bytes, "ms_per_step": round(mvs["ms"] / args.steps, 3),
+                         "note": "achieved = algorithmic 4 p rows bytes (the L_A block of this rank) / mean HIP-event duration "
+                                 "of the sweep kernel; the largest single-kernel share of the step"},
+            "nystroem": nystroem,
         }
         if skip_leg is not None:
             s_sec, s_info, s_avg_ms, s_stage = skip_leg

@@ -60,6 +60,12 @@ int glf_ctx_create(glf_ctx **out, int device, void *hip_stream)
             delete ctx;
             return GLF_ERR_HIP;
         }
+    for (auto &row : ctx->mv_ev)
+        for (auto &e : row)
+            if (hipEventCreate(&e) != hipSuccess) {
+                delete ctx;
+                return GLF_ERR_HIP;
+            }
     ctx->comm.rank = 0;
     ctx->comm.size = 1;
     if (const char *mode = std::getenv("GLF_CONTRACTION")) {
@@ -78,6 +84,9 @@ int glf_ctx_destroy(glf_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &row : ctx->mv_ev)
+        for (auto &e : row)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     glf::pool_free_all(ctx, false);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -396,6 +396,8 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
         // with tile skipping one workgroup per row block replays the dense run's slabs itself (bit-identical Y)
         const bool skipping = radius >= 0;
         dim3 grid((unsigned)nrb, skipping ? 1u : (unsigned)ksplit), block(256);
+        if (ctx->mv_pending == glf_ctx::MV_RING) GLF_TRY(mv_collect(ctx));
+        GLF_HIP(ctx, hipEventRecord(ctx->mv_ev[0][ctx->mv_pending], st));
         switch (ld / 32) {
         case 1: hipLaunchKernelGGL(k_block_matvec_f16s<1>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
         case 2: hipLaunchKernelGGL(k_block_matvec_f16s<2>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
@@ -403,6 +405,9 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
         case 8: hipLaunchKernelGGL(k_block_matvec_f16s<8>, grid, block, 0, st, A_eff, lda, p, p_pad, row0, row1, xfrag, scales, Y, ypart, kbox, radius, ksplit); break;
         default: return set_error(ctx, GLF_ERR_UNSUPPORTED, "ld %u", ld);
         }
+        GLF_HIP(ctx, hipEventRecord(ctx->mv_ev[1][ctx->mv_pending], st));
+        ++ctx->mv_pending;
+        ctx->mv_bytes += 4.0 * (double)p * (double)(row1 - row0); // the L_A block this rank streams (algorithmic bytes)
         if (ksplit > 1 && !skipping)
             hipLaunchKernelGGL(k_mv_sum_splits, dim3((unsigned)ceil_div((int64_t)(row1 - row0) * ld, 256)), dim3(256), 0, st, ypart,
                                ksplit, p_pad, row0, row1, ld, scales, Y);
@@ -413,6 +418,20 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
         if (ctx->comm.allgather_f32(ctx->comm.user, Y, (size_t)shard->rows_per_rank * ld) != 0)
             return set_error(ctx, GLF_ERR_COMM, "allgather_f32 callback failed");
     }
+    return GLF_OK;
+}
+
+int mv_collect(glf_ctx *ctx)
+{
+    if (ctx->mv_pending == 0) return GLF_OK;
+    GLF_HIP(ctx, hipEventSynchronize(ctx->mv_ev[1][ctx->mv_pending - 1]));
+    for (int i = 0; i < ctx->mv_pending; ++i) {
+        float ms = 0.f;
+        GLF_HIP(ctx, hipEventElapsedTime(&ms, ctx->mv_ev[0][i], ctx->mv_ev[1][i]));
+        ctx->mv_ms += ms;
+    }
+    ctx->mv_count += ctx->mv_pending;
+    ctx->mv_pending = 0;
     return GLF_OK;
 }
 
@@ -1312,6 +1331,9 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
     GLF_LAUNCH_CHECK(ctx);
 
+    GLF_TRY(mv_collect(ctx));
+    const int mv_count0 = ctx->mv_count;
+    const double mv_ms0 = ctx->mv_ms, mv_bytes0 = ctx->mv_bytes;
     GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :95
     // The reference leaves X_k_before_orth unset when the loop never runs (:97-101); define it.
     GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
@@ -1351,10 +1373,14 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         GLF_HIP(ctx, hipMemcpyAsync(d_eigvecs, Xb.p, sizeof(float) * n_out, hipMemcpyDeviceToDevice, st));
     }
     GLF_HIP(ctx, hipStreamSynchronize(st));
+    GLF_TRY(mv_collect(ctx));
     if (stats) {
         stats->outer_its = it;
         stats->inner_its_total = inner_total;
         stats->residual = r_norm;
+        stats->matvecs = ctx->mv_count - mv_count0;
+        stats->matvec_ms = (float)(ctx->mv_ms - mv_ms0);
+        stats->matvec_bytes = ctx->mv_bytes - mv_bytes0;
     }
     return rc;
 }

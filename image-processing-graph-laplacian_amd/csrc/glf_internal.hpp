@@ -34,6 +34,12 @@ struct glf_ctx {
     hipEvent_t ev[8] = {};
     void *mv_scratch = nullptr; // split-f16 X fragments of the block mat-vec
     size_t mv_scratch_bytes = 0;
+    // timing of the L_A sweeps (the HBM-bound kernel): a ring of event pairs, summed by mv_collect()
+    static constexpr int MV_RING = 64;
+    hipEvent_t mv_ev[2][MV_RING] = {};
+    int mv_pending = 0;
+    int mv_count = 0;
+    double mv_ms = 0.0, mv_bytes = 0.0;
     int contraction = GLF_CONTRACT_F16_SPLIT; // how glf_Nystroem / glf_image_processing contract K_B^T Psi
 };
 
@@ -187,6 +193,8 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
 
 // Same sums, skipping pixels whose kernel entry underflows to exactly 0 in f32 for every sample of a block
 // (h_idx: host sample indices, needed for the tile-major sample order). evaluated: entries executed.
+// sums the pending mat-vec event pairs into ctx->mv_ms (synchronises on the last one)
+int mv_collect(glf_ctx *ctx);
 int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
                      unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated);
 int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
@@ -243,7 +251,7 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float scale, const float *d_psi, unsigned m, unsigned ld,
                       float *d_phi, int raster, double *d_c, float *kernel_ms, int window = 0,
-                      uint64_t *entries_evaluated = nullptr);
+                      uint64_t *entries_evaluated = nullptr, double *mfma_flops = nullptr, int *path = nullptr);
 // box[c] = {rmin, rmax, cmin, cmax} of samples [64 c, 64 c + 64) (nystroem.hip)
 int chunk_boxes(glf_ctx *ctx, const float4 *d_samples, unsigned p, int4 *d_box);
 // Phi rows of the sample pixels <- Phi_A rows (hpc/nystroem.c:25-34 + hpc/utils.c:149-152)

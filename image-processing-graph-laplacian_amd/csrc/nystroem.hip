@@ -771,8 +771,13 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
 int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float /*scale folded into psi*/, const float *d_psi, unsigned m, unsigned ld,
-                      float *d_phi, int raster, double *d_c, float *kernel_ms, int window, uint64_t *entries_evaluated)
+                      float *d_phi, int raster, double *d_c, float *kernel_ms, int window, uint64_t *entries_evaluated,
+                      double *mfma_flops, int *path)
 {
+    uint64_t entries_local = 0;
+    if (!entries_evaluated) entries_evaluated = &entries_local;
+    if (path) *path = 0;
+    if (mfma_flops) *mfma_flops = 0.0;
     const int64_t N = (int64_t)width * height;
     if (pix0 < 0 || pix1 > N || pix0 > pix1 || !valid_ld(ld) || m > ld)
         return set_error(ctx, GLF_ERR_INVALID, "nystroem_contract: bad range or ld=%u", ld);
@@ -781,29 +786,35 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
     {
         // a tensor-grid sample set (hpc/sampling.c always yields one) takes the factored contraction
         const int rc = nystroem_contract_grid(ctx, d_img, width, height, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, ld,
-                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, nullptr);
-        if (rc != GLF_ERR_UNSUPPORTED) return rc;
+                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, mfma_flops);
+        if (rc != GLF_ERR_UNSUPPORTED) {
+            if (path) *path = 1;
+            return rc;
+        }
     }
+    int rc = GLF_ERR_UNSUPPORTED;
     if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
         switch (ld) {
-        case 32: return launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
-        case 64: return launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
-        case 128: return launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
-        case 256: return launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        case 32: rc = launch_nystroem_f16s<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
+        case 64: rc = launch_nystroem_f16s<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
+        case 128: rc = launch_nystroem_f16s<4, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
+        case 256: rc = launch_nystroem_f16s<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
         }
-        return GLF_ERR_UNSUPPORTED;
+        if (rc == GLF_OK && mfma_flops) *mfma_flops = 6.0 * (double)*entries_evaluated * ld;
+        return rc;
     }
     switch (ld) {
     case 32:
-        return launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        rc = launch_nystroem<1, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
     case 64:
-        return launch_nystroem<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        rc = launch_nystroem<2, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
     case 128:
-        return launch_nystroem<4, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        rc = launch_nystroem<4, 2>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
     case 256:
-        return launch_nystroem<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated);
+        rc = launch_nystroem<8, 1>(ctx, d_img, width, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, d_phi, raster, d_c, kernel_ms, window, entries_evaluated); break;
     }
-    return GLF_ERR_UNSUPPORTED;
+    if (rc == GLF_OK && mfma_flops) *mfma_flops = 2.0 * (double)*entries_evaluated * ld;
+    return rc;
 }
 
 // ---- sample rows: Phi[row(i)] = Phi_A[i]; c += Phi_A^T y_A -------------------------------------

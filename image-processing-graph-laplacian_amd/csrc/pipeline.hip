@@ -399,7 +399,8 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     float kms = 0.f;
     uint64_t evaluated = 0;
     GLF_TRY(nystroem_contract(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, (float)(-alpha),
-                              psi.p, m, ld, phi_base, 1, c.p, &kms, opt.skip_exact_zeros, &evaluated));
+                              psi.p, m, ld, phi_base, 1, c.p, &kms, opt.skip_exact_zeros, &evaluated, &S.nystroem_mfma_flops,
+                              &S.nystroem_path));
     S.nystroem_launches = 1;
     S.nystroem_kernel_ms = kms;
     S.contraction = ctx->contraction;

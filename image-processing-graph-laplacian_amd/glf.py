@@ -59,7 +59,8 @@ class Mat(C.Structure):
 
 
 class EigStats(C.Structure):
-    _fields_ = [("outer_its", C.c_int32), ("inner_its_total", C.c_int32), ("residual", C.c_double)]
+    _fields_ = [("outer_its", C.c_int32), ("inner_its_total", C.c_int32), ("residual", C.c_double),
+                ("matvecs", C.c_int32), ("matvec_ms", C.c_float), ("matvec_bytes", C.c_double)]
 
 
 class Options(C.Structure):
@@ -80,6 +81,7 @@ class Stats(C.Structure):
         ("nystroem_launches", C.c_int32), ("nystroem_kernel_ms", C.c_float),
         ("row0", C.c_int32), ("row1", C.c_int32), ("contraction", C.c_int32), ("skip_exact_zeros", C.c_int32),
         ("nystroem_evaluated", C.c_double), ("degree_evaluated", C.c_double),
+        ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -471,5 +473,7 @@ class Context:
                     nystroem_kernel_ms=st.nystroem_kernel_ms, nystroem_launches=st.nystroem_launches,
                     row0=st.row0, row1=st.row1, contraction=st.contraction, skip_exact_zeros=st.skip_exact_zeros,
                     nystroem_evaluated=st.nystroem_evaluated, degree_evaluated=st.degree_evaluated,
+                    nystroem_mfma_flops=st.nystroem_mfma_flops, nystroem_path=st.nystroem_path,
+                    matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     eigvals=lam[:st.m].copy())
         return out, zf, info

@@ -171,6 +171,11 @@ int glf_ComputeLaplacianMatrix(glf_ctx *ctx, glf_mat *L_A, glf_mat *L_B, const g
 typedef struct glf_eig_stats {
     int32_t outer_its, inner_its_total;
     double residual;
+    /* the L_A sweeps (block mat-vecs) of the solve: launches, summed device ms (HIP events around the sweep kernel on
+     * the context's stream) and the L_A bytes this rank streamed (4 p rows_of_the_rank per sweep) */
+    int32_t matvecs;
+    float matvec_ms;
+    double matvec_bytes;
 } glf_eig_stats;
 
 /* void InversePowerIteration(const Mat A, unsigned m, Mat* eigvecs, Mat* eigvals,
@@ -247,8 +252,13 @@ typedef struct glf_stats {
     int32_t row0, row1;     /* this rank's pixel rows */
     int32_t contraction;    /* GLF_CONTRACT_* actually used */
     int32_t skip_exact_zeros;
-    /* kernel evaluations actually executed by this rank (dense: p * pixels of the rank) */
+    /* kernel entries covered by this rank (dense: p * pixels of the rank), evaluated one by one (direct kernels)
+     * or through the factored sums of the grid forms */
     double nystroem_evaluated, degree_evaluated;
+    /* f16 MFMA flops issued by the Nystroem contraction (3 products per split multiply-add) */
+    double nystroem_mfma_flops;
+    int32_t nystroem_path;  /* 0 direct kernel (K_B generated entry by entry), 1 grid-factored */
+    int32_t reserved;
 } glf_stats;
 
 /* ApproximationComputation, hpc/image_processing.c:183-277 (commented tail

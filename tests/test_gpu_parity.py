@@ -209,12 +209,13 @@ def test_nystroem_permutation_filter(ctx, golden, png, name, m):
 
 
 @pytest.mark.parametrize("w,h,ns,m", [(128, 96, 150, 8), (192, 64, 300, 40), (64, 200, 90, 64)])
-def test_nystroem_lut_matches_exp_generation(ctx, w, h, ns, m, monkeypatch):
-    """width % 64 == 0 selects the table-driven kernel generation (k_nystroem_f16s<.., LUT>); GLF_NYS_NO_LUT forces
-    the v_exp_f32 variant. Both must match the fp64 oracle, and each other far below that tolerance."""
+def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
+    """Three implementations of the same contraction: the grid-factored form (default for the tensor-grid sample
+    sets hpc/sampling.c produces), the direct kernel with table-driven generation (GLF_NYS_NO_GRID, width % 64 == 0)
+    and the direct kernel with v_exp_f32 (GLF_NYS_NO_LUT). Each must match the fp64 oracle, and each other far
+    below that tolerance."""
     img = glf.synth_image(w, h, seed=5)
     idx = glf.Sampling(w, h, ns)
-    p = idx.size
     KA, _ = orc.affinity(img, idx, want_KB=False)
     LA, alpha = orc.laplacian(KA, orc.degree(img, idx))
     vecs, vals = _lapack_pairs(LA, m)
@@ -225,20 +226,67 @@ def test_nystroem_lut_matches_exp_generation(ctx, w, h, ns, m, monkeypatch):
     phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
     Pi_inv = ctx.InverseDiagMat(Pi)
     got = {}
-    for mode in ("lut", "exp"):
-        if mode == "exp":
-            monkeypatch.setenv("GLF_NYS_NO_LUT", "1")
-        else:
-            monkeypatch.delenv("GLF_NYS_NO_LUT", raising=False)
+    for mode, env in (("grid", {}), ("lut", {"GLF_NYS_NO_GRID": "1"}), ("exp", {"GLF_NYS_NO_GRID": "1", "GLF_NYS_NO_LUT": "1"})):
+        for k in ("GLF_NYS_NO_GRID", "GLF_NYS_NO_LUT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         phi = ctx.Nystroem(L_B, phi_A, Pi_inv)
         got[mode] = ctx.mat_to_numpy(phi)
         ctx.destroy(phi)
-    monkeypatch.delenv("GLF_NYS_NO_LUT", raising=False)
+    for k in ("GLF_NYS_NO_GRID", "GLF_NYS_NO_LUT"):
+        monkeypatch.delenv(k, raising=False)
     scale = np.abs(ref).max()
     for mode in got:
         np.testing.assert_allclose(got[mode], ref, rtol=0, atol=2e-4 * scale, err_msg=mode)
     np.testing.assert_allclose(got["lut"], got["exp"], rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(got["grid"], got["exp"], rtol=0, atol=2e-5 * scale)
     ctx.destroy(L_A, phi_A, Pi, Pi_inv, K_B)
+
+
+@pytest.mark.parametrize("w,h,ns", [(128, 96, 150), (450, 300, 1350), (77, 200, 60)])
+def test_degree_paths_agree(ctx, w, h, ns, monkeypatch):
+    """D_A from the grid-factored form (default) and from the direct sweep (GLF_DEG_NO_GRID) against the oracle."""
+    img = glf.synth_image(w, h, seed=9)
+    idx = glf.Sampling(w, h, ns)
+    ref = orc.degree(img, idx)
+    d_img = ctx.to_device(img)
+    got = {}
+    for mode in ("grid", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("GLF_DEG_NO_GRID", "1")
+        else:
+            monkeypatch.delenv("GLF_DEG_NO_GRID", raising=False)
+        _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+        got[mode] = ctx.degree_of(K_B)
+        ctx.destroy(K_B)
+    monkeypatch.delenv("GLF_DEG_NO_GRID", raising=False)
+    for mode in got:
+        np.testing.assert_allclose(got[mode], ref, rtol=2e-6, err_msg=mode)
+    np.testing.assert_allclose(got["grid"], got["direct"], rtol=5e-7)
+
+
+def test_non_grid_sample_set_takes_the_direct_kernels(ctx):
+    """The stage API accepts any ascending sample set (hpc/affinity.h:5); one that is not a tensor grid must fall
+    back to the direct kernels and still match the oracle."""
+    w, h, m = 128, 64, 8
+    img = glf.synth_image(w, h, seed=21)
+    rng = np.random.default_rng(3)
+    idx = np.sort(rng.choice(w * h, size=90, replace=False)).astype(np.uint32)
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    deg_ref = orc.degree(img, idx)
+    LA, alpha = orc.laplacian(KA, deg_ref)
+    vecs, vals = _lapack_pairs(LA, m)
+    ref = orc.nystroem(img, idx, alpha, vecs, vals).T
+    d_img = ctx.to_device(img)
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    np.testing.assert_allclose(ctx.degree_of(K_B), deg_ref, rtol=2e-6)
+    L_A, L_B, _ = ctx.ComputeLaplacianMatrix(None, K_B)
+    phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
+    Pi_inv = ctx.InverseDiagMat(Pi)
+    phi = ctx.Nystroem(L_B, phi_A, Pi_inv)
+    np.testing.assert_allclose(ctx.mat_to_numpy(phi), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+    ctx.destroy(L_A, phi_A, Pi, Pi_inv, K_B, phi)
 
 
 def test_filter_golden_from_python_poc(ctx, golden, png):
@@ -393,10 +441,14 @@ def test_errors_are_loud(ctx):
     assert out.dtype == torch.uint8
 
 
-def test_exact_zero_skipping_is_bit_identical(ctx):
+@pytest.mark.parametrize("paths", ["grid", "direct"])
+def test_exact_zero_skipping_is_bit_identical(ctx, paths, monkeypatch):
     """glf_options.skip_exact_zeros drops whole 64-sample chunks whose kernel entries are exactly zero
     in the arithmetic in use; the result must not change by a single bit, only the executed work."""
     import torch
+    if paths == "direct":        # the entry-by-entry kernels instead of the grid-factored forms
+        monkeypatch.setenv("GLF_NYS_NO_GRID", "1")
+        monkeypatch.setenv("GLF_DEG_NO_GRID", "1")
     img = glf.synth_image(1280, 1024, seed=11)
     d_img = ctx.to_device(img)
     ns = int(1280 * 1024 * 0.005)
