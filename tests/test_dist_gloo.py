@@ -81,11 +81,14 @@ def test_two_rank_gloo_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["gpu", "gpu_replicated"])
-def test_two_ranks_share_one_gpu(tmp_path, mode):
+@pytest.mark.parametrize("mode,paths", [("gpu", "direct"), ("gpu_replicated", "direct"), ("gpu", "grid")])
+def test_two_ranks_share_one_gpu(tmp_path, mode, paths, monkeypatch):
     """mode gpu: L_A column-sharded, mat-vec rows all-gathered; gpu_replicated: no allgather
-    callback, every rank solves the whole eigenproblem. Both must reproduce the single-rank run."""
+    callback, every rank solves the whole eigenproblem. Both must reproduce the single-rank run.
+    paths: the entry-by-entry kernels or the grid-factored forms (which shard by image rows too)."""
     import torch
+    monkeypatch.setenv("GLF_NYS_PATH", paths)   # inherited by the rank processes
+    monkeypatch.setenv("GLF_DEG_PATH", paths)
     assert torch.cuda.is_available()
     pattern = str(tmp_path / "gpu_rank%d.npz")
     _launch(mode, pattern, timeout=600)

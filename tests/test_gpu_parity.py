@@ -210,9 +210,9 @@ def test_nystroem_permutation_filter(ctx, golden, png, name, m):
 
 @pytest.mark.parametrize("w,h,ns,m", [(128, 96, 150, 8), (192, 64, 300, 40), (64, 200, 90, 64)])
 def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
-    """Three implementations of the same contraction: the grid-factored form (default for the tensor-grid sample
-    sets hpc/sampling.c produces), the direct kernel with table-driven generation (GLF_NYS_NO_GRID, width % 64 == 0)
-    and the direct kernel with v_exp_f32 (GLF_NYS_NO_LUT). Each must match the fp64 oracle, and each other far
+    """Three implementations of the same contraction: the grid-factored form (GLF_NYS_PATH=grid; the default from
+    1024-pixel-wide images on, for the tensor-grid sample sets hpc/sampling.c produces), the direct kernel with
+    table-driven generation (GLF_NYS_PATH=direct, width % 64 == 0) and the direct kernel with v_exp_f32 (GLF_NYS_NO_LUT). Each must match the fp64 oracle, and each other far
     below that tolerance."""
     img = glf.synth_image(w, h, seed=5)
     idx = glf.Sampling(w, h, ns)
@@ -226,15 +226,16 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
     phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
     Pi_inv = ctx.InverseDiagMat(Pi)
     got = {}
-    for mode, env in (("grid", {}), ("lut", {"GLF_NYS_NO_GRID": "1"}), ("exp", {"GLF_NYS_NO_GRID": "1", "GLF_NYS_NO_LUT": "1"})):
-        for k in ("GLF_NYS_NO_GRID", "GLF_NYS_NO_LUT"):
+    for mode, env in (("grid", {"GLF_NYS_PATH": "grid"}), ("lut", {"GLF_NYS_PATH": "direct"}),
+                      ("exp", {"GLF_NYS_PATH": "direct", "GLF_NYS_NO_LUT": "1"})):
+        for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         phi = ctx.Nystroem(L_B, phi_A, Pi_inv)
         got[mode] = ctx.mat_to_numpy(phi)
         ctx.destroy(phi)
-    for k in ("GLF_NYS_NO_GRID", "GLF_NYS_NO_LUT"):
+    for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT"):
         monkeypatch.delenv(k, raising=False)
     scale = np.abs(ref).max()
     for mode in got:
@@ -246,21 +247,18 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
 
 @pytest.mark.parametrize("w,h,ns", [(128, 96, 150), (450, 300, 1350), (77, 200, 60)])
 def test_degree_paths_agree(ctx, w, h, ns, monkeypatch):
-    """D_A from the grid-factored form (default) and from the direct sweep (GLF_DEG_NO_GRID) against the oracle."""
+    """D_A from the grid-factored form (GLF_DEG_PATH=grid) and from the direct sweep (=direct) against the oracle."""
     img = glf.synth_image(w, h, seed=9)
     idx = glf.Sampling(w, h, ns)
     ref = orc.degree(img, idx)
     d_img = ctx.to_device(img)
     got = {}
     for mode in ("grid", "direct"):
-        if mode == "direct":
-            monkeypatch.setenv("GLF_DEG_NO_GRID", "1")
-        else:
-            monkeypatch.delenv("GLF_DEG_NO_GRID", raising=False)
+        monkeypatch.setenv("GLF_DEG_PATH", mode)
         _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
         got[mode] = ctx.degree_of(K_B)
         ctx.destroy(K_B)
-    monkeypatch.delenv("GLF_DEG_NO_GRID", raising=False)
+    monkeypatch.delenv("GLF_DEG_PATH", raising=False)
     for mode in got:
         np.testing.assert_allclose(got[mode], ref, rtol=2e-6, err_msg=mode)
     np.testing.assert_allclose(got["grid"], got["direct"], rtol=5e-7)
@@ -336,6 +334,25 @@ def test_image_processing_end_to_end(ctx, golden, png, name, ns, m, eps):
         assert rel_l2 <= 1e-4
         assert psnr(out, out_ref) >= 50.0
         assert np.mean(np.abs(out.astype(int) - out_ref.astype(int)) <= 1) >= 0.99
+
+
+@pytest.mark.parametrize("name,ns,m,eps", [("ragged", 20, 5, 0.1), ("cat50", 50, 53, 0.1), ("test", 100, 16, 0.1)])
+def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, monkeypatch):
+    """The grid-factored degree and Nystroem contraction are chosen automatically from 1024-pixel-wide images on;
+    forced here on the small reference images (odd widths, m up to p - 1) against the fp64 oracle."""
+    monkeypatch.setenv("GLF_NYS_PATH", "grid")
+    monkeypatch.setenv("GLF_DEG_PATH", "grid")
+    img, _ = _images(golden, png)[name]
+    zf_ref, out_ref, ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
+    out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
+                                         want_float=True)
+    if info["contraction"] == glf.CONTRACT_F16_SPLIT:
+        assert info["nystroem_path"] == 1
+    assert info["alpha"] == pytest.approx(ref["alpha"], rel=2e-6)
+    assert abs(info["outer_its"] - ref["outer_its"]) <= 1
+    if info["outer_its"] == ref["outer_its"]:
+        assert psnr(out.cpu().numpy(), out_ref) >= 50.0
+        assert np.linalg.norm(zf.cpu().numpy() - zf_ref) / np.linalg.norm(zf_ref) <= 1e-4
 
 
 def test_barbara_config2(ctx, golden, png):
@@ -446,9 +463,8 @@ def test_exact_zero_skipping_is_bit_identical(ctx, paths, monkeypatch):
     """glf_options.skip_exact_zeros drops whole 64-sample chunks whose kernel entries are exactly zero
     in the arithmetic in use; the result must not change by a single bit, only the executed work."""
     import torch
-    if paths == "direct":        # the entry-by-entry kernels instead of the grid-factored forms
-        monkeypatch.setenv("GLF_NYS_NO_GRID", "1")
-        monkeypatch.setenv("GLF_DEG_NO_GRID", "1")
+    monkeypatch.setenv("GLF_NYS_PATH", paths)   # the grid-factored forms or the entry-by-entry kernels
+    monkeypatch.setenv("GLF_DEG_PATH", paths)
     img = glf.synth_image(1280, 1024, seed=11)
     d_img = ctx.to_device(img)
     ns = int(1280 * 1024 * 0.005)

@@ -12,8 +12,7 @@ for (W, H, frac, m) in cases:
         opt.skip_exact_zeros = skip
         outs = {}
         for mode in ("grid", "direct"):
-            if mode == "direct": os.environ["GLF_NYS_NO_GRID"] = "1"; os.environ["GLF_DEG_NO_GRID"] = "1"
-            else: os.environ.pop("GLF_NYS_NO_GRID", None); os.environ.pop("GLF_DEG_NO_GRID", None)
+            os.environ["GLF_NYS_PATH"] = mode; os.environ["GLF_DEG_PATH"] = mode
             ctx.image_processing(d_img, opt)
             out, zf, info = ctx.image_processing(d_img, opt, want_float=True)
             outs[mode] = (out.cpu().numpy(), zf.cpu().numpy(), info)
