@@ -1069,6 +1069,7 @@ struct GsWork {
     DevBuf<double> partial, norms, q, normpart;
     DevBuf<float> coef;
     GsFusedWork fused;
+    bool last_fused = false; // the last orthonormalise_dev took the Gram-matrix form (fused.Tn holds X_new = X_old Tn)
     int nblk = 0;
     int init(glf_ctx *ctx, unsigned n, unsigned ld)
     {
@@ -1134,10 +1135,14 @@ static int orthonormalise_seq_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n,
 static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld)
 {
     const char *mode = std::getenv("GLF_GS");
+    w.last_fused = false;
     if (!(mode && std::strcmp(mode, "seq") == 0)) {
         int fell_back = 0;
         GLF_TRY(orthonormalise_fused_dev(ctx, w.fused, X, n, m, ld, w.norms.p, &fell_back));
-        if (!fell_back) return GLF_OK;
+        if (!fell_back) {
+            w.last_fused = true;
+            return GLF_OK;
+        }
         if (std::getenv("GLF_VERBOSE")) fprintf(stderr, "[glf] Gram-Schmidt: ill-conditioned block, column-by-column sweep\n");
     }
     return orthonormalise_seq_dev(ctx, w, X, n, m, ld);
@@ -1261,13 +1266,14 @@ struct ResWork {
     }
 };
 
+// ax_ready: w.AX already holds A X (derived from the PCG state, see inverse_power_iteration) -- no sweep over L_A
 static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
-                        unsigned ld, double *h_out)
+                        unsigned ld, double *h_out, bool ax_ready = false)
 {
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const int nblk = (int)ceil_div(p, RED_ROWS);
     hipStream_t st = ctx->stream;
-    GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld, w.shard));
+    if (!ax_ready) GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld, w.shard));
     const int mb = ld / 32;
     hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X, w.AX.p, p32, ld, w.Gpart.p);
     hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 255) / 256), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
@@ -1283,9 +1289,21 @@ static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, u
     return GLF_OK;
 }
 
+// out[i] -= r[i]
+__global__ void k_sub_inplace(float *__restrict__ out, const float *__restrict__ r, size_t n)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] -= r[e];
+}
+
 // =====================================================================================
 // InversePowerIteration, hpc/inverse_power_it.c:86-252
 // =====================================================================================
+//
+// The residual of every outer iteration needs A X_new (hpc/inverse_power_it.c:49-80, :180). X_new = Y Tn with
+// Y the PCG solution of A Y = B (B = the previous X) and Tn the triangular map of the Gram-Schmidt, and the PCG
+// carries R = B - A Y, so A X_new = (B - R) Tn without another 4 p^2-byte sweep over L_A. Used whenever the
+// Gram-Schmidt took the Gram-matrix form (or was skipped by opti_gs); GLF_RESIDUAL=sweep forces the explicit sweep.
 
 int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
                             const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
@@ -1342,6 +1360,8 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     const bool verbose = std::getenv("GLF_VERBOSE") != nullptr; // the reference logs every outer iteration (:164-181)
     if (verbose) fprintf(stderr, "[glf rank %d] initial residual %.9g\n", ctx->comm.rank, r_norm);
     int it = 0, inner_total = 0, rc = GLF_OK;
+    const char *res_mode = std::getenv("GLF_RESIDUAL");
+    const bool derive_ax = !(res_mode && std::strcmp(res_mode, "sweep") == 0);
     while (r_norm > epsilon) { // :161
         if (it >= max_outer) {
             rc = set_error(ctx, GLF_ERR_NOCONV, "inverse iteration: residual %g > %g after %d outer iterations", r_norm,
@@ -1350,12 +1370,24 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         }
         ++it;
         int inner = 0;
+        const size_t npl = (size_t)p * ld;
+        if (derive_ax) GLF_HIP(ctx, hipMemcpyAsync(rs.AX.p, X.p, sizeof(float) * npl, hipMemcpyDeviceToDevice, st)); // B
         GLF_TRY(block_pcg_work(ctx, cg, A, lda, p, X.p, m, ld, inner_rtol, 10 * (int)p + 100, &inner)); // :165-168
         inner_total += inner;
         GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st)); // CopyVecs :171
-        if (it % opti_gs == 0)
+        bool ax_ready = derive_ax;
+        if (derive_ax) // A Y = B - R
+            hipLaunchKernelGGL(k_sub_inplace, dim3((unsigned)ceil_div((int64_t)npl, 256)), dim3(256), 0, st, rs.AX.p, cg.R.p, npl);
+        if (it % opti_gs == 0) {
             GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :174-177
-        GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :180
+            if (ax_ready && gs.last_fused) // A X_new = (A Y) Tn
+                hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(p, 8192 / ld)), dim3(256), 0, st, rs.AX.p, p, ld, m,
+                                   gs.fused.Tn.p, gs.fused.flag.p);
+            else
+                ax_ready = false; // column-by-column sweep: no triangular map at hand
+        }
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm, ax_ready)); // :180
         if (verbose)
             fprintf(stderr, "[glf rank %d] outer iteration %d: %d block-CG steps, residual %.9g\n", ctx->comm.rank, it, inner, r_norm);
     }
