@@ -487,7 +487,11 @@ __global__ __launch_bounds__(256) void k_sample_matrix(const float4 *__restrict_
 {
     const unsigned jl = blockIdx.x * 64 + (threadIdx.x & 63); // local column
     const unsigned i0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
-    if (jl >= ncols) return;
+    if (jl >= (unsigned)ld) return;
+    if (jl >= ncols) { // padding columns up to the leading dimension: zeros (no separate memset of the 4 p ld bytes)
+        for (unsigned ii = 0; ii < 16 && i0 + ii < p; ++ii) out[(size_t)(i0 + ii) * ld + jl] = 0.f;
+        return;
+    }
     const unsigned j = col0 + jl;
     const float4 sj = samples[j];
     const float fscale = laplacian ? (float)(-alpha) : 1.0f;
@@ -511,7 +515,7 @@ int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, Kerne
         ncols = p;
     }
     if (col0 + ncols > p) return set_error(ctx, GLF_ERR_INVALID, "build_sample_matrix: column range");
-    dim3 grid((ncols + 63) / 64, (p + 63) / 64);
+    dim3 grid((unsigned)((ld + 63) / 64), (p + 63) / 64); // covers the padding columns too
     hipLaunchKernelGGL(k_sample_matrix, grid, dim3(256), 0, ctx->stream, d_samples, p, coef.s_loc, coef.s_val, d_out,
                        ld, laplacian ? 1 : 0, alpha, d_degree, col0, ncols);
     GLF_LAUNCH_CHECK(ctx);

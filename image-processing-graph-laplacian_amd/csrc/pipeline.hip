@@ -352,8 +352,7 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     const int64_t lda = shard_eig ? round_up(la_cols ? la_cols : 1, VEC_PAD) : (int64_t)p32;
     DevBuf<float> LA, dinv;
     GLF_TRY(LA.alloc(ctx, (size_t)p * lda));
-    GLF_HIP(ctx, hipMemsetAsync(LA.p, 0, sizeof(float) * (size_t)p * lda, st));
-    if (la_cols)
+    if (la_cols) // writes every element of the p x lda block, padding columns included
         GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, lda, true, alpha, deg.p, shard_eig ? shard.row0 : 0u, la_cols));
     GLF_TRY(dinv.alloc(ctx, p));
     hipLaunchKernelGGL(k_dinv_from_degree, dim3((p + 255) / 256), dim3(256), 0, st, deg.p, p, alpha, dinv.p);
