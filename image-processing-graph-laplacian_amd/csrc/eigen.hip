@@ -421,6 +421,29 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
     return GLF_OK;
 }
 
+int start_block_cached(glf_ctx *ctx, unsigned p, unsigned m, unsigned ld, unsigned long long seed, const float **d_block)
+{
+    if (!ctx->x0_block || ctx->x0_p != p || ctx->x0_m != m || ctx->x0_ld != ld || ctx->x0_seed != seed) {
+        const size_t n = (size_t)round_up(p, VEC_PAD) * ld;
+        std::vector<double> x0((size_t)m * p);
+        glf_random_vectors(x0.data(), p, m, seed);
+        std::vector<float> h(n, 0.f);
+        for (unsigned j = 0; j < m; ++j)
+            for (unsigned i = 0; i < p; ++i) h[(size_t)i * ld + j] = (float)x0[(size_t)j * p + i];
+        if (ctx->x0_block) (void)hipFree(ctx->x0_block);
+        ctx->x0_block = nullptr;
+        GLF_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->x0_block), n * sizeof(float)));
+        GLF_HIP(ctx, hipMemcpyAsync(ctx->x0_block, h.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->x0_p = p;
+        ctx->x0_m = m;
+        ctx->x0_ld = ld;
+        ctx->x0_seed = seed;
+    }
+    *d_block = ctx->x0_block;
+    return GLF_OK;
+}
+
 int mv_collect(glf_ctx *ctx)
 {
     if (ctx->mv_pending == 0) return GLF_OK;
@@ -1308,7 +1331,7 @@ __global__ void k_sub_inplace(float *__restrict__ out, const float *__restrict__
 int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
                             const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
                             float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats, const MatShard *shard,
-                            const float *d_dinv)
+                            const float *d_dinv, const float *d_X0_block)
 {
     if (m == 0 || m > p || !valid_ld(ld) || m > ld)
         return set_error(ctx, GLF_ERR_INVALID, "inverse_power_iteration: m=%u ld=%u p=%u (m <= 256 supported)", m, ld, p);
@@ -1321,8 +1344,11 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     DevBuf<float> X, Xb;
     GLF_TRY(X.alloc(ctx, n));
     GLF_TRY(Xb.alloc(ctx, n));
-    // X0: host double [m][p] (vector after vector) -> device float [p32][ld]
-    {
+    // X0: a ready device block [p32][ld], or host double [m][p] (vector after vector) -> device float [p32][ld]
+    if (d_X0_block) {
+        GLF_HIP(ctx, hipMemsetAsync(X.p, 0, sizeof(float) * n, st));
+        GLF_HIP(ctx, hipMemcpyAsync(X.p, d_X0_block, sizeof(float) * n_out, hipMemcpyDeviceToDevice, st));
+    } else {
         std::vector<double> own;
         if (!h_X0) {
             own.resize((size_t)m * p);

@@ -40,6 +40,11 @@ struct glf_ctx {
     int mv_pending = 0;
     int mv_count = 0;
     double mv_ms = 0.0, mv_bytes = 0.0;
+    // the seeded random start block of the eigensolver (hpc/inverse_power_it.c:12-47) as a device [p64][ld] f32 block:
+    // it depends on (p, m, ld, seed) only, so images of one size reuse it (17 ms of host time at cfg4)
+    float *x0_block = nullptr;
+    unsigned x0_p = 0, x0_m = 0, x0_ld = 0;
+    unsigned long long x0_seed = 0;
     int contraction = GLF_CONTRACT_F16_SPLIT; // how glf_Nystroem / glf_image_processing contract K_B^T Psi
 };
 
@@ -195,6 +200,8 @@ int degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int r
 // (h_idx: host sample indices, needed for the tile-major sample order). evaluated: entries executed.
 // sums the pending mat-vec event pairs into ctx->mv_ms (synchronises on the last one)
 int mv_collect(glf_ctx *ctx);
+// device pointer to the cached start block X0 [round_up(p,64)][ld] for (p, m, ld, seed)
+int start_block_cached(glf_ctx *ctx, unsigned p, unsigned m, unsigned ld, unsigned long long seed, const float **d_block);
 int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
                      unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated);
 int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
@@ -242,7 +249,8 @@ int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, doubl
 int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, unsigned ld,
                             const double *h_X0, int opti_gs, double epsilon, double inner_rtol, int max_outer,
                             float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats,
-                            const MatShard *shard = nullptr, const float *d_dinv = nullptr);
+                            const MatShard *shard = nullptr, const float *d_dinv = nullptr,
+                            const float *d_X0_block = nullptr);
 
 // Nystroem contraction (nystroem.hip): Phi[pix][j] = sum_i scale*K(sample i, pix) * Psi[i][j]
 // for pixels [pix0, pix1). raster != 0: row = pix; else sample-first (rows of sample pixels skipped).

@@ -363,11 +363,11 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     GLF_TRY(phiA.alloc(ctx, (size_t)p32 * ld));
     std::vector<double> lam(m);
     {
-        std::vector<double> X0((size_t)m * p);
-        glf_random_vectors(X0.data(), p, m, opt.seed);
-        int rc = inverse_power_iteration(ctx, LA.p, lda, p, m, ld, X0.data(), opt.opti_gs, opt.epsilon, opt.inner_rtol,
+        const float *d_x0 = nullptr; // seeded start block (hpc/inverse_power_it.c:12-47), cached per (p, m, ld, seed)
+        GLF_TRY(start_block_cached(ctx, p, m, ld, opt.seed, &d_x0));
+        int rc = inverse_power_iteration(ctx, LA.p, lda, p, m, ld, nullptr, opt.opti_gs, opt.epsilon, opt.inner_rtol,
                                          opt.max_outer > 0 ? opt.max_outer : 100000, phiA.p, lam.data(), &S.eig,
-                                         (shard_eig || shard.kbox) ? &shard : nullptr, dinv.p);
+                                         (shard_eig || shard.kbox) ? &shard : nullptr, dinv.p, d_x0);
         if (rc != GLF_OK) return rc;
     }
     LA.release();
