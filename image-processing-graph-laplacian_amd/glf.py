@@ -260,14 +260,14 @@ class Context:
         return dict(name=name.value.decode(), num_cus=cus.value, total_mem=mem.value)
 
     # -- collectives ---------------------------------------------------------------------------
-    def set_comm_torch(self, group=None, shard_eigensolve=True):
+    def set_comm_torch(self, group=None, shard_eigensolve=True, force=False):
         """Plug torch.distributed all-reduces into glf_comm: RCCL on the device buffers in place
         (backend "nccl"), or staged through host memory for a gloo group (CPU rehearsal of the
         N > 1 path, several ranks sharing one GPU in tests)."""
         import torch.distributed as dist
         torch = self.torch
         size, rank = dist.get_world_size(group), dist.get_rank(group)
-        if size == 1:
+        if size == 1 and not force:   # force: keep the callbacks on a one-rank group (tests the device collectives)
             self._check(_lib.glf_ctx_set_comm(self._ctx, None))
             return
         dev = self.device

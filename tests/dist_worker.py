@@ -6,6 +6,10 @@ mode cpu: gloo on the CPU. Exercises the N > 1 host logic without a GPU: the row
           buffers) and the two all-reduces of the sharded path, with the fp64 oracle standing in
           for the device stages (test infrastructure only).
 mode gpu: the real HIP path, ranks sharing cuda:0, collectives staged through gloo.
+mode gpu_nccl1: ONE rank, backend nccl (= RCCL): the device-side callbacks bench.py uses at N > 1 (in-place all-reduce /
+          all-gather on torch views of the library's raw device pointers, ordered on the context's stream) with a
+          communicator forced on although the world has one rank. Two ranks cannot share a GPU under RCCL, so this is
+          as close as a one-GPU box gets to the N > 1 collectives.
 """
 import ctypes as C
 import json
@@ -88,11 +92,11 @@ def run_cpu(out_path):
              outer=st["outer_its"], Y=Y[:p], Yref=(LA @ vecs.T).astype(np.float32))
 
 
-def run_gpu(out_path, shard_eigensolve=True):
+def run_gpu(out_path, shard_eigensolve=True, force=False):
     rank = dist.get_rank()
     img = glf.synth_image(96, 80, seed=4)
     with glf.Context(0) as ctx:
-        ctx.set_comm_torch(shard_eigensolve=shard_eigensolve)
+        ctx.set_comm_torch(shard_eigensolve=shard_eigensolve, force=force)
         opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
         out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
         np.savez(out_path % rank, out=out.cpu().numpy(), zf=zf.cpu().numpy(), rows=np.array([info["row0"], info["row1"]]),
@@ -101,10 +105,16 @@ def run_gpu(out_path, shard_eigensolve=True):
 
 if __name__ == "__main__":
     mode, out_path = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    if mode == "gpu_nccl1":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     try:
         if mode == "cpu":
             run_cpu(out_path)
+        elif mode == "gpu_nccl1":
+            run_gpu(out_path, shard_eigensolve=True, force=True)
         else:
             run_gpu(out_path, shard_eigensolve=(mode == "gpu"))
     finally:

@@ -110,3 +110,22 @@ def test_two_ranks_share_one_gpu(tmp_path, mode, paths, monkeypatch):
     assert np.mean(out != out1) < 1e-3
     # rows a rank does not own stay untouched (zero-initialised by the binding)
     assert not r[0]["out"][a1:].any() and not r[1]["out"][:b0].any()
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_device_collectives(tmp_path):
+    """The callbacks bench.py plugs in at N > 1 (torch.distributed backend "nccl" = RCCL, in place on the library's device
+    buffers, on the context's stream) on a one-rank group with the communicator forced on: sharded eigen-solve with the
+    all-gather callback, both all-reduces. Must reproduce the run without a communicator."""
+    pattern = str(tmp_path / "nccl_rank%d.npz")
+    _launch("gpu_nccl1", pattern, world=1, timeout=600)
+    r = np.load(pattern % 0)
+    img = glf.synth_image(96, 80, seed=4)
+    with glf.Context(0) as ctx:
+        opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
+        out1, zf1, info1 = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    assert tuple(r["rows"]) == (0, img.shape[0])
+    assert int(r["outer"]) == info1["outer_its"]
+    np.testing.assert_allclose(r["eigvals"], info1["eigvals"], rtol=1e-5)
+    np.testing.assert_allclose(r["zf"], zf1.cpu().numpy(), rtol=0, atol=5e-4)
+    assert np.mean(r["out"] != out1.cpu().numpy()) < 1e-3
