@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--no-skip-leg", action="store_true",
                     help="do not time the extra exact-zero-skipping leg (reported beside the headline)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="diagnostic: one rank, but with the RCCL callbacks plugged in (cost of the N > 1 plumbing)")
     return ap.parse_args()
 
 
@@ -133,8 +135,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world
@@ -146,8 +149,8 @@ def main():
     N = size * size
     img = glf.synth_image(size, size, seed=0)      # byte-identical on every rank
     ctx = glf.Context(local_rank)
-    if world > 1:
-        ctx.set_comm_torch()
+    if world > 1 or args.force_comm:
+        ctx.set_comm_torch(force=args.force_comm)
     d_img = ctx.to_device(img)
     d_out = torch.zeros((size, size), dtype=torch.uint8, device=ctx.device)
     opt = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals, epsilon=args.epsilon)
@@ -285,7 +288,7 @@ def main():
             line["cpu_baseline"]["parity_cfg2"] = cpu_parity_cfg2(ctx)
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if world > 1 or args.force_comm:
         dist.barrier()
         dist.destroy_process_group()
 
