@@ -487,16 +487,44 @@ int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const fl
 // Small helpers: fixed-order sums of per-block partials
 // =====================================================================================
 
-constexpr int RED_ROWS = 512; // rows per reduction workgroup
+constexpr int RED_ROWS = 128; // rows per reduction workgroup (667 workgroups at p = 85 264: every CU busy)
 
 // out[c] = sum_blk partial[blk][c], c < ncols
-__global__ void k_sum_partials(const double *__restrict__ partial, int nblk, int ncols, double *__restrict__ out)
+// Second level of the column reductions, one 256-thread workgroup: out[v] (valid for t < ld) = sum over the nblk
+// blocks of partial[(b * NV + v) * ld + t % ld]. The 256 / ld thread rows take interleaved blocks and are combined
+// through LDS -- all in a fixed order.
+template <int NV>
+__device__ __forceinline__ void wg_sum_partials(const double *__restrict__ partial, int nblk, unsigned ld, double (&out)[NV],
+                                                double *sh /* [NV][256] */)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * ncols + c];
-    out[c] = s;
+    const int t = threadIdx.x, col = t % ld, part = t / ld, nparts = 256 / ld;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (int b = part; b < nblk; b += nparts)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += partial[((size_t)b * NV + v) * ld + col];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sh[v * 256 + t] = acc[v];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double s = 0.0;
+        if (t < (int)ld)
+            for (int r = 0; r < nparts; ++r) s += sh[v * 256 + r * ld + col];
+        out[v] = s;
+    }
+    __syncthreads();
+}
+
+// out[c] = sum_blk partial[blk][c], c < ld (one workgroup of 256 threads)
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partial, int nblk, int ncols,
+                                                       double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double s[1];
+    wg_sum_partials<1>(partial, nblk, (unsigned)ncols, s, sh);
+    if ((int)threadIdx.x < ncols) out[threadIdx.x] = s[0];
 }
 
 // Block-level column reduction helper: 256 threads, column = t % ld, row lane = t / ld.
@@ -559,15 +587,15 @@ __global__ __launch_bounds__(256) void k_cg_init(const float *__restrict__ B, co
     block_col_reduce<2>(v, ld, partial, sh);
 }
 
-__global__ void k_cg_init_scalars(const double *__restrict__ partial, int nblk, unsigned ld, unsigned m, CgScalars s)
+__global__ __launch_bounds__(256) void k_cg_init_scalars(const double *__restrict__ partial, int nblk, unsigned ld, unsigned m,
+                                                          CgScalars s)
 {
+    __shared__ double sh[2 * 256];
     const int c = threadIdx.x;
+    double tot[2];
+    wg_sum_partials<2>(partial, nblk, ld, tot, sh);
     if (c < (int)ld) {
-        double rz = 0.0, bn2 = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            rz += partial[((size_t)b * 2 + 0) * ld + c];
-            bn2 += partial[((size_t)b * 2 + 1) * ld + c];
-        }
+        const double rz = tot[0], bn2 = tot[1];
         s.rz[c] = rz;
         s.bn2[c] = bn2;
         s.active[c] = (c < (int)m && bn2 > 0.0) ? 1 : 0;
@@ -599,13 +627,13 @@ __global__ __launch_bounds__(256) void k_cg_dot(const float *__restrict__ P, con
     block_col_reduce<1>(v, ld, partial, sh);
 }
 
-__global__ void k_cg_alpha(const double *__restrict__ partial, int nblk, unsigned ld, CgScalars s)
+__global__ __launch_bounds__(256) void k_cg_alpha(const double *__restrict__ partial, int nblk, unsigned ld, CgScalars s)
 {
+    __shared__ double sh[256];
     const int c = threadIdx.x;
-    if (c >= (int)ld) return;
-    double pap = 0.0;
-    for (int b = 0; b < nblk; ++b) pap += partial[(size_t)b * ld + c];
-    s.alpha[c] = s.active[c] ? s.rz[c] / pap : 0.0;
+    double pap[1];
+    wg_sum_partials<1>(partial, nblk, ld, pap, sh);
+    if (c < (int)ld) s.alpha[c] = s.active[c] ? s.rz[c] / pap[0] : 0.0;
 }
 
 // x += alpha p ; r -= alpha Ap ; partial ||r||^2 and r.(dinv r)
@@ -635,15 +663,15 @@ __global__ __launch_bounds__(256) void k_cg_update(float *__restrict__ Xs, float
     block_col_reduce<2>(v, ld, partial, sh);
 }
 
-__global__ void k_cg_beta(const double *__restrict__ partial, int nblk, unsigned ld, double rtol2, CgScalars s)
+__global__ __launch_bounds__(256) void k_cg_beta(const double *__restrict__ partial, int nblk, unsigned ld, double rtol2,
+                                                  CgScalars s)
 {
+    __shared__ double sh[2 * 256];
     const int c = threadIdx.x;
+    double tot[2];
+    wg_sum_partials<2>(partial, nblk, ld, tot, sh);
     if (c < (int)ld && s.active[c]) {
-        double rr = 0.0, rz = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            rr += partial[((size_t)b * 2 + 0) * ld + c];
-            rz += partial[((size_t)b * 2 + 1) * ld + c];
-        }
+        const double rr = tot[0], rz = tot[1];
         if (rr <= rtol2 * s.bn2[c]) { // ||r|| <= rtol ||b||
             s.active[c] = 0;
             s.beta[c] = 0.0;
@@ -880,13 +908,13 @@ __global__ __launch_bounds__(256) void k_col_sumsq(const float *__restrict__ X, 
     block_col_reduce<1>(v, ld, partial, sh);
 }
 
-__global__ void k_norms_from_partials(const double *__restrict__ partial, int nblk, unsigned ld, double *__restrict__ norms)
+__global__ __launch_bounds__(256) void k_norms_from_partials(const double *__restrict__ partial, int nblk, unsigned ld,
+                                                              double *__restrict__ norms)
 {
-    const int c = threadIdx.x;
-    if (c >= (int)ld) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * ld + c];
-    norms[c] = sqrt(s);
+    __shared__ double sh[256];
+    double s[1];
+    wg_sum_partials<1>(partial, nblk, ld, s, sh);
+    if (threadIdx.x < ld) norms[threadIdx.x] = sqrt(s[0]);
 }
 
 __global__ void k_scale_all(float *__restrict__ X, unsigned n, unsigned ld, unsigned m, const double *__restrict__ norms)
@@ -1208,7 +1236,7 @@ int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, doubl
 // Residual || (I - X X^T) A X ||_F  (hpc/inverse_power_it.c:49-80) as || AX - X (X^T AX) ||_F
 // =====================================================================================
 
-constexpr int GRAM_ROWS = 1024; // rows per Gram workgroup chunk
+constexpr int GRAM_ROWS = 256; // rows per Gram workgroup chunk
 
 // Gpart[chunk][a][b] = sum_{i in chunk} X[i][a] * Y[i][b]; one wave per 32x32 (a,b) tile.
 __global__ __launch_bounds__(64) void k_gram(const float *__restrict__ X, const float *__restrict__ Y, unsigned p32,
@@ -1233,13 +1261,18 @@ __global__ __launch_bounds__(64) void k_gram(const float *__restrict__ X, const 
     }
 }
 
-__global__ void k_gram_sum(const float *__restrict__ Gpart, int nchunks, unsigned ld, float *__restrict__ G)
+// 64 entries per workgroup; the 4 thread rows take interleaved chunks (fixed order)
+__global__ __launch_bounds__(256) void k_gram_sum(const float *__restrict__ Gpart, int nchunks, unsigned ld, float *__restrict__ G)
 {
-    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ld * ld) return;
+    __shared__ double sh[256];
+    const unsigned e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += (double)Gpart[(size_t)c * ld * ld + e];
-    G[e] = (float)s;
+    if (e < ld * ld)
+        for (int c = part; c < nchunks; c += 4) s += (double)Gpart[(size_t)c * ld * ld + e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && e < ld * ld) G[e] = (float)((sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]));
 }
 
 // partial[blk][b] = sum_i (Y[i][b] - sum_a X[i][a] G[a][b])^2
@@ -1299,7 +1332,7 @@ static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, u
     if (!ax_ready) GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld, w.shard));
     const int mb = ld / 32;
     hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X, w.AX.p, p32, ld, w.Gpart.p);
-    hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 255) / 256), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
+    hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
     hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X, w.AX.p, w.G.p, p, ld, m, w.partial.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, w.partial.p, nblk, (int)ld, w.sums.p);
     GLF_LAUNCH_CHECK(ctx);
