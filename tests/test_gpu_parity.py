@@ -502,10 +502,14 @@ def test_entire_computation_no_approx(ctx, png, shape):
     assert 0 < alpha < 1
 
 
+@pytest.mark.parametrize("paths", ["direct", "grid"])
 @pytest.mark.parametrize("w,h,ns,m", [(16, 12, 6, 2), (24, 31, 9, 3), (200, 160, 500, 128), (256, 256, 655, 256)])
-def test_extreme_shapes_end_to_end(ctx, w, h, ns, m):
+def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     """Tiny images (p < one 64-sample chunk) and the widest supported blocks (ld = 128, 256: the MB = 4 / 8
-    kernel instantiations) against the oracle. m = 256 is the stated upper limit of this build."""
+    instantiations of the direct kernel, two / four 64-column blocks of the grid form) against the oracle.
+    m = 256 is the stated upper limit of this build."""
+    monkeypatch.setenv("GLF_NYS_PATH", paths)
+    monkeypatch.setenv("GLF_DEG_PATH", paths)
     img = glf.synth_image(w, h, seed=21)
     eps = 0.2
     zf_ref, out_ref, ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
@@ -513,6 +517,8 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m):
     out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
     out, zf = out.cpu().numpy(), zf.cpu().numpy()
     assert (info["p"], info["m"]) == (ref["p"], ref["m"])
+    if paths == "grid" and info["contraction"] == glf.CONTRACT_F16_SPLIT and info["p"] >= 4:
+        assert info["nystroem_path"] == 1
     assert info["alpha"] == pytest.approx(ref["alpha"], rel=2e-6)
     assert abs(info["outer_its"] - ref["outer_its"]) <= 1
     if info["outer_its"] == ref["outer_its"]:
