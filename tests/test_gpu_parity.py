@@ -524,3 +524,31 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     if info["outer_its"] == ref["outer_its"]:
         assert np.linalg.norm(zf - zf_ref) / np.linalg.norm(zf_ref) <= 1e-4
         assert psnr(out, out_ref) >= 50.0
+
+
+@pytest.mark.parametrize("w,h,ns", [(320, 1536, 30720), (1408, 200, 17600)])
+def test_grid_forms_with_many_grid_rows_or_columns(ctx, w, h, ns, monkeypatch):
+    """More than 304 grid rows (the Psi slice of the grid row pass no longer fits the LDS beside the A slice and comes
+    from global memory) and more than 320 grid columns: grid forms against the direct kernels, dense and skipping."""
+    import torch
+    img = glf.synth_image(w, h, seed=2)
+    d_img = ctx.to_device(img)
+    res = {}
+    for paths in ("grid", "direct"):
+        monkeypatch.setenv("GLF_NYS_PATH", paths)
+        monkeypatch.setenv("GLF_DEG_PATH", paths)
+        for skip in (0, 1):
+            opt = glf.default_options(num_samples=ns, num_eigvals=24, epsilon=0.2, skip_exact_zeros=skip)
+            out, zf, info = ctx.image_processing(d_img, opt, want_float=True)
+            res[paths, skip] = (zf.clone(), info)
+    g = glf.Sampling(w, h, ns)
+    assert res["grid", 0][1]["p"] == g.size
+    if res["grid", 0][1]["contraction"] == glf.CONTRACT_F16_SPLIT:
+        assert res["grid", 0][1]["nystroem_path"] == 1
+    for paths in ("grid", "direct"):   # skipping is bit-identical within a family
+        assert torch.equal(res[paths, 0][0].view(torch.int32), res[paths, 1][0].view(torch.int32))
+    a, b = res["grid", 0], res["direct", 0]
+    assert a[1]["alpha"] == pytest.approx(b[1]["alpha"], rel=1e-6)
+    assert a[1]["outer_its"] == b[1]["outer_its"]
+    rel = float(torch.linalg.norm(a[0].double() - b[0].double()) / torch.linalg.norm(b[0].double()))
+    assert rel < 1e-6
