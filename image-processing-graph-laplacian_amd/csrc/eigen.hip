@@ -463,6 +463,20 @@ int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const fl
 {
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const bool sharded = shard && shard->rows_per_rank;
+    if (shard && shard->grid) { // L_A applied in grid-factored form (never stored): rows [row0, row1) are whole grid rows
+        const unsigned row0 = sharded ? shard->row0 : 0u, row1 = sharded ? shard->row1 : p;
+        if (ctx->mv_pending == glf_ctx::MV_RING) GLF_TRY(mv_collect(ctx));
+        GLF_HIP(ctx, hipEventRecord(ctx->mv_ev[0][ctx->mv_pending], ctx->stream));
+        GLF_TRY(grid_op_apply(ctx, shard->grid, X, Y, ld, shard->grid_alpha, shard->grid_degree, row0, row1, shard->grid_window));
+        GLF_HIP(ctx, hipEventRecord(ctx->mv_ev[1][ctx->mv_pending], ctx->stream));
+        ++ctx->mv_pending;
+        if (sharded) {
+            if (!ctx->has_comm || !ctx->comm.allgather_f32) return set_error(ctx, GLF_ERR_COMM, "sharded mat-vec without allgather_f32");
+            if (ctx->comm.allgather_f32(ctx->comm.user, Y, (size_t)shard->rows_per_rank * ld) != 0)
+                return set_error(ctx, GLF_ERR_COMM, "allgather_f32 callback failed");
+        }
+        return GLF_OK;
+    }
     if (sharded && ctx->contraction != GLF_CONTRACT_F16_SPLIT)
         return set_error(ctx, GLF_ERR_UNSUPPORTED, "row-sharded mat-vec needs the split-f16 contraction");
     if ((!sharded && lda < (int64_t)p32) || (lda & 3) || !valid_ld(ld))

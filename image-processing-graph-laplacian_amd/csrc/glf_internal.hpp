@@ -225,8 +225,21 @@ int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, 
 // rows [row0,row1) of A X and holds only the matching COLUMN block A[:, row0:row1) (= the transposed row
 // block), stored [p][lda] with element (k, row) at A[k * lda + (row - row0)]. rows_per_rank is the
 // all-gather block (a multiple of 64 >= ceil(p / size)); 0 = not sharded (A is the full matrix).
+struct GridOp; // L_A = alpha (D - K_A) applied in grid-factored form, never stored (nystroem_grid.inc)
+int grid_op_create(glf_ctx *ctx, const float4 *d_samples, const unsigned *h_idx, unsigned p, int width, int height,
+                   KernelCoef coef, GridOp **out); // GLF_ERR_UNSUPPORTED: not a tensor grid (or not the split-f16 mode)
+void grid_op_destroy(GridOp *op);
+unsigned grid_op_rows_per_rank(const GridOp *op, int size); // all-gather block: whole grid rows
+int grid_op_apply(glf_ctx *ctx, GridOp *op, const float *X, float *Y, unsigned ld, double alpha, const double *d_degree,
+                  unsigned row0, unsigned row1, int window);
+
 struct MatShard {
     unsigned row0 = 0, row1 = 0, rows_per_rank = 0;
+    // when set, the operator is applied through the grid-factored form and `A` is not used (may be null)
+    GridOp *grid = nullptr;
+    double grid_alpha = 0.0;
+    const double *grid_degree = nullptr;
+    int grid_window = 0;
     // Exact-zero tile skipping of the split-f16 mat-vec (optional): kbox[c] = bounding box {rmin, rmax,
     // cmin, cmax} of samples [64 c, 64 c + 64); a (128-row block, 64-k tile) pair whose boxes are more
     // than `radius` pixels apart holds only entries with |2^10 A| < 2^-25, i.e. f16 hi = lo = 0.

@@ -3,6 +3,7 @@
 #include "glf_internal.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 
 namespace glf {
@@ -333,15 +334,35 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     // mat-vec. Otherwise (single GPU, f32 contraction, or no allgather callback) L_A is whole.
     MatShard shard;
     const bool shard_eig = ctx->has_comm && ctx->comm.allgather_f32 && ctx->contraction == GLF_CONTRACT_F16_SPLIT;
+    // For a tensor-grid sample set L_A is applied in grid-factored form and never stored (GLF_MV_PATH = grid | dense | auto;
+    // auto: from 16 384 samples on -- below, streaming a small stored L_A is cheaper than the factored sweep's fixed cost)
+    struct GridOpGuard {
+        GridOp *op = nullptr;
+        ~GridOpGuard() { grid_op_destroy(op); }
+    } gop;
+    {
+        const char *mv = std::getenv("GLF_MV_PATH");
+        const bool want = mv && std::strcmp(mv, "grid") == 0 ? true : mv && std::strcmp(mv, "dense") == 0 ? false : p >= 16384;
+        if (want) {
+            const int rc = grid_op_create(ctx, tb.samples.p, h_idx, p, width, height, coef, &gop.op);
+            if (rc != GLF_OK && rc != GLF_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    if (gop.op) {
+        shard.grid = gop.op;
+        shard.grid_alpha = alpha;
+        shard.grid_degree = deg.p;
+        shard.grid_window = opt.skip_exact_zeros;
+    }
     if (shard_eig) {
-        shard.rows_per_rank = shard_rows_per_rank(p, ctx->comm.size);
+        shard.rows_per_rank = gop.op ? grid_op_rows_per_rank(gop.op, ctx->comm.size) : shard_rows_per_rank(p, ctx->comm.size);
         const uint64_t b = (uint64_t)shard.rows_per_rank * (unsigned)ctx->comm.rank;
         shard.row0 = (unsigned)(b < p ? b : p);
         shard.row1 = (unsigned)(b + shard.rows_per_rank < p ? b + shard.rows_per_rank : p);
     }
     // Exact-zero tile skipping of the mat-vec: |2^10 L_A[i][j]| = 2^10 alpha K < 2^-25 once t > 35 + log2(alpha)
     DevBuf<int4> kbox;
-    if (opt.skip_exact_zeros && coef.s_loc > 0.f && ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
+    if (!gop.op && opt.skip_exact_zeros && coef.s_loc > 0.f && ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
         const double t_zero = 35.5 + std::log2(alpha);
         GLF_TRY(kbox.alloc(ctx, (size_t)ceil_div(p, 64)));
         GLF_TRY(chunk_boxes(ctx, tb.samples.p, p, kbox.p));
@@ -351,9 +372,11 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     const unsigned la_cols = shard_eig ? shard.row1 - shard.row0 : p;
     const int64_t lda = shard_eig ? round_up(la_cols ? la_cols : 1, VEC_PAD) : (int64_t)p32;
     DevBuf<float> LA, dinv;
-    GLF_TRY(LA.alloc(ctx, (size_t)p * lda));
-    if (la_cols) // writes every element of the p x lda block, padding columns included
-        GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, lda, true, alpha, deg.p, shard_eig ? shard.row0 : 0u, la_cols));
+    if (!gop.op) {
+        GLF_TRY(LA.alloc(ctx, (size_t)p * lda));
+        if (la_cols) // writes every element of the p x lda block, padding columns included
+            GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, lda, true, alpha, deg.p, shard_eig ? shard.row0 : 0u, la_cols));
+    }
     GLF_TRY(dinv.alloc(ctx, p));
     hipLaunchKernelGGL(k_dinv_from_degree, dim3((p + 255) / 256), dim3(256), 0, st, deg.p, p, alpha, dinv.p);
     GLF_LAUNCH_CHECK(ctx);
@@ -367,7 +390,7 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
         GLF_TRY(start_block_cached(ctx, p, m, ld, opt.seed, &d_x0));
         int rc = inverse_power_iteration(ctx, LA.p, lda, p, m, ld, nullptr, opt.opti_gs, opt.epsilon, opt.inner_rtol,
                                          opt.max_outer > 0 ? opt.max_outer : 100000, phiA.p, lam.data(), &S.eig,
-                                         (shard_eig || shard.kbox) ? &shard : nullptr, dinv.p, d_x0);
+                                         (shard_eig || shard.kbox || shard.grid) ? &shard : nullptr, dinv.p, d_x0);
         if (rc != GLF_OK) return rc;
     }
     LA.release();

@@ -89,6 +89,7 @@ def test_two_ranks_share_one_gpu(tmp_path, mode, paths, monkeypatch):
     import torch
     monkeypatch.setenv("GLF_NYS_PATH", paths)   # inherited by the rank processes
     monkeypatch.setenv("GLF_DEG_PATH", paths)
+    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
     assert torch.cuda.is_available()
     pattern = str(tmp_path / "gpu_rank%d.npz")
     _launch(mode, pattern, timeout=600)

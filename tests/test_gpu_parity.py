@@ -342,6 +342,7 @@ def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, m
     forced here on the small reference images (odd widths, m up to p - 1) against the fp64 oracle."""
     monkeypatch.setenv("GLF_NYS_PATH", "grid")
     monkeypatch.setenv("GLF_DEG_PATH", "grid")
+    monkeypatch.setenv("GLF_MV_PATH", "grid")
     img, _ = _images(golden, png)[name]
     zf_ref, out_ref, ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
     out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
@@ -465,6 +466,7 @@ def test_exact_zero_skipping_is_bit_identical(ctx, paths, monkeypatch):
     import torch
     monkeypatch.setenv("GLF_NYS_PATH", paths)   # the grid-factored forms or the entry-by-entry kernels
     monkeypatch.setenv("GLF_DEG_PATH", paths)
+    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
     img = glf.synth_image(1280, 1024, seed=11)
     d_img = ctx.to_device(img)
     ns = int(1280 * 1024 * 0.005)
@@ -510,6 +512,7 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     m = 256 is the stated upper limit of this build."""
     monkeypatch.setenv("GLF_NYS_PATH", paths)
     monkeypatch.setenv("GLF_DEG_PATH", paths)
+    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
     img = glf.synth_image(w, h, seed=21)
     eps = 0.2
     zf_ref, out_ref, ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
@@ -537,6 +540,7 @@ def test_grid_forms_with_many_grid_rows_or_columns(ctx, w, h, ns, monkeypatch):
     for paths in ("grid", "direct"):
         monkeypatch.setenv("GLF_NYS_PATH", paths)
         monkeypatch.setenv("GLF_DEG_PATH", paths)
+        monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
         for skip in (0, 1):
             opt = glf.default_options(num_samples=ns, num_eigvals=24, epsilon=0.2, skip_exact_zeros=skip)
             out, zf, info = ctx.image_processing(d_img, opt, want_float=True)
