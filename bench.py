@@ -171,6 +171,7 @@ def main():
         t0 = time.perf_counter()
         kernel_ms = []
         mv = {"launches": 0, "ms": 0.0, "bytes": 0.0}
+        rp = {"launches": 0, "ms": 0.0, "flops": 0.0}
         stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
         for _ in range(args.steps):
             _, _, info = ctx.image_processing(d_img, opt, out=d_out)
@@ -178,6 +179,9 @@ def main():
             mv["launches"] += info["matvecs"]
             mv["ms"] += info["matvec_ms"]
             mv["bytes"] += info["matvec_bytes"]
+            rp["launches"] += info["nystroem_rowpass_launches"]
+            rp["ms"] += info["nystroem_rowpass_ms"]
+            rp["flops"] += info["nystroem_rowpass_flops"]
             for k in stage_ms:
                 stage_ms[k] += info[k]
         barrier()
@@ -187,6 +191,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         info["mv"] = mv
+        info["rp"] = rp
         return elapsed / args.steps, info, float(np.mean(kernel_ms)), {k[3:]: round(v / args.steps, 3) for k, v in stage_ms.items()}
 
     sec_per_step, info, avg_ms, stage_ms = run_leg(opt)
@@ -236,18 +241,47 @@ def main():
                     "computes the same sums with 2 H 256 nc nr m + 2 N nc m flop, so algorithmic_tflops may exceed the MFMA "
                     "peak; mfma_issued counts the f16 MFMA flops actually executed (x3 for the split products)",
         }
-        # dominant kernel of the step: the L_A sweep of the eigensolver (k_block_matvec_f16s), HBM-bound
-        mvs = info["mv"]
+        # ---- the L_A sweeps of the eigensolver, and the dominant kernel of the step ---------------------------
+        mvs, rps = info["mv"], info["rp"]
         mv_avg_ms = mvs["ms"] / max(1, mvs["launches"])
-        mv_bytes = mvs["bytes"] / max(1, mvs["launches"])          # algorithmic: 4 p (rows of this rank) per launch
-        mv_gbs = mv_bytes / (mv_avg_ms * 1e-3) / 1e9 if mv_avg_ms > 0 else 0.0
-        traffic = None
+        prof = {}
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this configuration
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             key = "%dx%d_m%d_%s_gpus%d" % (size, size, m, "f16s" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32", n_gpus)
-            traffic = prof.get(key, {}).get("matvec_bytes_per_launch")
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(key, {})
         except (OSError, ValueError):
             pass
+        sweeps = {"path": "grid-factored (L_A never stored)" if info["matvec_path"] == 1 else "stored L_A streamed (k_block_matvec_f16s)",
+                  "launches_per_step": mvs["launches"] / args.steps, "avg_ms": round(mv_avg_ms, 4),
+                  "ms_per_step": round(mvs["ms"] / args.steps, 3)}
+        if info["matvec_path"] == 1 and rps["launches"] > 0:
+            # dominant kernel: k_grid_rowpass (the inner sums of the Nystroem contraction and of every L_A sweep)
+            rp_avg_ms = rps["ms"] / rps["launches"]
+            rp_flops = rps["flops"] / rps["launches"]
+            rp_tflops = rp_flops / (rp_avg_ms * 1e-3) / 1e12
+            rp_peak = PEAK_F16_MFMA_TFLOPS / 3.0
+            roofline = {
+                "kernel": "k_grid_rowpass<%d> (T[r][v][b] = sum_a P(|v - v_ab|) Er(r - R_a) Psi[(a,b)]: GEMM per sample column b on "
+                          "v_mfma_f32_32x32x16_f16, both operands split into f16 hi+lo, f32 accumulate; timed here on the launches of "
+                          "the Nystroem stage, the L_A sweeps of the eigensolver run the same kernel on the grid rows)" % (min(ld, 64) // 32),
+                "bound": "mfma", "achieved": round(rp_tflops, 1), "peak": round(rp_peak, 1), "unit": "TFLOP/s",
+                "frac": round(rp_tflops / rp_peak, 4), "traffic": prof.get("grid_rowpass_bytes_per_launch"),
+                "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add",
+                "avg_launch_ms": round(rp_avg_ms, 4), "launches_per_step": rps["launches"] / args.steps,
+                "flops_per_launch": rp_flops, "ms_per_step": round(rps["ms"] / args.steps, 3),
+                "note": "achieved = algorithmic 2 rows 256 nc nr m flop of the launch (one product per multiply-add) / mean "
+                        "HIP-event duration of the launch; traffic = its T write (FETCH_SIZE x 2 + WRITE_SIZE, --pmc passes)"}
+        else:
+            mv_bytes = mvs["bytes"] / max(1, mvs["launches"])          # algorithmic: 4 p (rows of this rank) per launch
+            mv_gbs = mv_bytes / (mv_avg_ms * 1e-3) / 1e9 if mv_avg_ms > 0 else 0.0
+            roofline = {
+                "kernel": "k_block_matvec_f16s<%d> (block mat-vec of the PCG / residual: L_A streamed once per launch, "
+                          "split-f16 MFMA contraction with the %d-column block)" % (ld // 32, ld),
+                "bound": "hbm", "achieved": round(mv_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(mv_gbs / PEAK_HBM_GBS, 4), "traffic": prof.get("matvec_bytes_per_launch"),
+                "avg_launch_ms": round(mv_avg_ms, 4), "launches_per_step": mvs["launches"] / args.steps,
+                "bytes_per_launch": mv_bytes, "ms_per_step": round(mvs["ms"] / args.steps, 3),
+                "note": "achieved = algorithmic 4 p rows bytes (the L_A block of this rank) / mean HIP-event duration of the "
+                        "sweep kernel; the largest single-kernel share of the step"}
         line = {
             "metric": "filtered Mpixels/sec @ 4K img, 0.5% samples",
             "value": round(value, 4), "unit": "Mpixel/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -260,14 +294,8 @@ def main():
                        "contraction": "f16 split (hi+lo), f32 accumulate" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32 MFMA",
                        "sharding": "pixel rows / %d ranks; L_A column blocks / %d ranks" % (n_gpus, n_gpus)},
             "stage_ms_rank0": stage_ms,
-            "roofline": {"kernel": "k_block_matvec_f16s<%d> (block mat-vec of the PCG / residual: L_A streamed once per launch, "
-                                   "split-f16 MFMA contraction with the %d-column block)" % (ld // 32, ld),
-                         "bound": "hbm", "achieved": round(mv_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(mv_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
-                         "avg_launch_ms": round(mv_avg_ms, 4), "launches_per_step": mvs["launches"] / args.steps,
-                         "bytes_per_launch": mv_bytes, "ms_per_step": round(mvs["ms"] / args.steps, 3),
-                         "note": "achieved = algorithmic 4 p rows bytes (the L_A block of this rank) / mean HIP-event duration "
-                                 "of the sweep kernel; the largest single-kernel share of the step"},
+            "roofline": roofline,
+            "eigen_sweeps": sweeps,
             "nystroem": nystroem,
         }
         if skip_leg is not None:

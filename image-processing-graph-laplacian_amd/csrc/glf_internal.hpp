@@ -225,6 +225,12 @@ int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, 
 // rows [row0,row1) of A X and holds only the matching COLUMN block A[:, row0:row1) (= the transposed row
 // block), stored [p][lda] with element (k, row) at A[k * lda + (row - row0)]. rows_per_rank is the
 // all-gather block (a multiple of 64 >= ceil(p / size)); 0 = not sharded (A is the full matrix).
+// the row-pass kernel of the grid-factored Nystroem contraction, timed launch by launch
+struct RowpassStats {
+    int launches = 0;
+    float ms = 0.f;
+    double flops = 0.0;
+};
 struct GridOp; // L_A = alpha (D - K_A) applied in grid-factored form, never stored (nystroem_grid.inc)
 int grid_op_create(glf_ctx *ctx, const float4 *d_samples, const unsigned *h_idx, unsigned p, int width, int height,
                    KernelCoef coef, GridOp **out); // GLF_ERR_UNSUPPORTED: not a tensor grid (or not the split-f16 mode)
@@ -272,7 +278,8 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float scale, const float *d_psi, unsigned m, unsigned ld,
                       float *d_phi, int raster, double *d_c, float *kernel_ms, int window = 0,
-                      uint64_t *entries_evaluated = nullptr, double *mfma_flops = nullptr, int *path = nullptr);
+                      uint64_t *entries_evaluated = nullptr, double *mfma_flops = nullptr, int *path = nullptr,
+                      RowpassStats *rowpass = nullptr);
 // box[c] = {rmin, rmax, cmin, cmax} of samples [64 c, 64 c + 64) (nystroem.hip)
 int chunk_boxes(glf_ctx *ctx, const float4 *d_samples, unsigned p, int4 *d_box);
 // Phi rows of the sample pixels <- Phi_A rows (hpc/nystroem.c:25-34 + hpc/utils.c:149-152)

@@ -774,7 +774,7 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
                       const float4 *d_samples, const uint8_t *d_mask, const uint32_t *d_idx, unsigned p,
                       KernelCoef coef, float /*scale folded into psi*/, const float *d_psi, unsigned m, unsigned ld,
                       float *d_phi, int raster, double *d_c, float *kernel_ms, int window, uint64_t *entries_evaluated,
-                      double *mfma_flops, int *path)
+                      double *mfma_flops, int *path, RowpassStats *rowpass)
 {
     uint64_t entries_local = 0;
     if (!entries_evaluated) entries_evaluated = &entries_local;
@@ -788,7 +788,7 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
     {
         // a tensor-grid sample set (hpc/sampling.c always yields one) takes the factored contraction
         const int rc = nystroem_contract_grid(ctx, d_img, width, height, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, ld,
-                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, mfma_flops);
+                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, mfma_flops, rowpass);
         if (rc != GLF_ERR_UNSUPPORTED) {
             if (path) *path = 1;
             return rc;

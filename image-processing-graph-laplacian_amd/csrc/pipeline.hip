@@ -348,6 +348,7 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
             if (rc != GLF_OK && rc != GLF_ERR_UNSUPPORTED) return rc;
         }
     }
+    S.matvec_path = gop.op ? 1 : 0;
     if (gop.op) {
         shard.grid = gop.op;
         shard.grid_alpha = alpha;
@@ -420,9 +421,13 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     GLF_HIP(ctx, hipMemsetAsync(c.p, 0, sizeof(double) * ld, st));
     float kms = 0.f;
     uint64_t evaluated = 0;
+    RowpassStats rps;
     GLF_TRY(nystroem_contract(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, (float)(-alpha),
                               psi.p, m, ld, phi_base, 1, c.p, &kms, opt.skip_exact_zeros, &evaluated, &S.nystroem_mfma_flops,
-                              &S.nystroem_path));
+                              &S.nystroem_path, &rps));
+    S.nystroem_rowpass_launches = rps.launches;
+    S.nystroem_rowpass_ms = rps.ms;
+    S.nystroem_rowpass_flops = rps.flops;
     S.nystroem_launches = 1;
     S.nystroem_kernel_ms = kms;
     S.contraction = ctx->contraction;

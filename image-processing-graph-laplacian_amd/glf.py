@@ -81,7 +81,8 @@ class Stats(C.Structure):
         ("nystroem_launches", C.c_int32), ("nystroem_kernel_ms", C.c_float),
         ("row0", C.c_int32), ("row1", C.c_int32), ("contraction", C.c_int32), ("skip_exact_zeros", C.c_int32),
         ("nystroem_evaluated", C.c_double), ("degree_evaluated", C.c_double),
-        ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("reserved", C.c_int32),
+        ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("matvec_path", C.c_int32),
+        ("nystroem_rowpass_launches", C.c_int32), ("nystroem_rowpass_ms", C.c_float), ("nystroem_rowpass_flops", C.c_double),
     ]
 
 
@@ -473,7 +474,9 @@ class Context:
                     nystroem_kernel_ms=st.nystroem_kernel_ms, nystroem_launches=st.nystroem_launches,
                     row0=st.row0, row1=st.row1, contraction=st.contraction, skip_exact_zeros=st.skip_exact_zeros,
                     nystroem_evaluated=st.nystroem_evaluated, degree_evaluated=st.degree_evaluated,
-                    nystroem_mfma_flops=st.nystroem_mfma_flops, nystroem_path=st.nystroem_path,
+                    nystroem_mfma_flops=st.nystroem_mfma_flops, nystroem_path=st.nystroem_path, matvec_path=st.matvec_path,
+                    nystroem_rowpass_launches=st.nystroem_rowpass_launches, nystroem_rowpass_ms=st.nystroem_rowpass_ms,
+                    nystroem_rowpass_flops=st.nystroem_rowpass_flops,
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     eigvals=lam[:st.m].copy())
         return out, zf, info

@@ -258,7 +258,12 @@ typedef struct glf_stats {
     /* f16 MFMA flops issued by the Nystroem contraction (3 products per split multiply-add) */
     double nystroem_mfma_flops;
     int32_t nystroem_path;  /* 0 direct kernel (K_B generated entry by entry), 1 grid-factored */
-    int32_t reserved;
+    int32_t matvec_path;    /* 0 stored L_A streamed per sweep, 1 L_A applied in grid-factored form (never stored) */
+    /* grid-factored Nystroem: the row-pass kernel (k_grid_rowpass) alone -- launches, summed device ms (HIP events around
+     * each launch) and its algorithmic flops 2 rows 256 nc nr ld (one product per multiply-add) */
+    int32_t nystroem_rowpass_launches;
+    float nystroem_rowpass_ms;
+    double nystroem_rowpass_flops;
 } glf_stats;
 
 /* ApproximationComputation, hpc/image_processing.c:183-277 (commented tail
