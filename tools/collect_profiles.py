@@ -24,6 +24,7 @@ for name in ("bench_plain", "bench_under_rocprof"):
         json.dump(json.loads(line), open(os.path.join(dst, "%s_%s.json" % (tag, name.replace("_plain", ""))), "w"), indent=1)
 
 summary = collections.defaultdict(dict)
+series = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -38,9 +39,20 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             c = r["Counter_Name"]
             summary[k][c] = summary[k].get(c, 0.0) + float(r["Counter_Value"])
             calls[k][c] += 1
+            # the same kernel serves launches of very different size (k_grid_rowpass: the Nystroem passes and the much
+            # smaller L_A sweeps): keep the per-dispatch series to tell them apart by their WRITE_SIZE
+            series[k].setdefault(c, []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     for k in calls:
         summary[k]["calls"] = max(calls[k].values())
         summary[k]["total_ms_pass_" + os.path.basename(d)[4:]] = round(dur.get(k, 0.0), 3)
+for k in list(series):
+    if "k_grid_rowpass" in k and "WRITE_SIZE" in series[k] and "FETCH_SIZE" in series[k]:
+        w = [v for _, v in sorted(series[k]["WRITE_SIZE"])]
+        f = [v for _, v in sorted(series[k]["FETCH_SIZE"])]
+        if len(w) == len(f) and w:
+            big = [i for i, v in enumerate(w) if v > 0.5 * max(w)]   # the Nystroem passes (dispatch order is the same in every run)
+            summary[k + "@nystroem_passes"] = {"WRITE_SIZE": sum(w[i] for i in big), "FETCH_SIZE": sum(f[i] for i in big),
+                                               "calls": len(big)}
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
 nys = [k for k in summary if "k_nystroem_f16s" in k and "FETCH_SIZE" in summary[k]]
@@ -64,7 +76,8 @@ for name, key in (("k_block_matvec_f16s", "matvec"), ("k_grid_rowpass", "grid_ro
     ks = [k for k in summary if name in k and "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]]
     if not ks:
         continue
-    k = max(ks, key=lambda k: summary[k]["FETCH_SIZE"])
+    pref = [k for k in ks if k.endswith("@nystroem_passes")]
+    k = pref[0] if pref else max(ks, key=lambda k: summary[k]["FETCH_SIZE"] + summary[k]["WRITE_SIZE"])
     fetch = summary[k]["FETCH_SIZE"] / summary[k]["calls"] * 1024.0 * 2.0
     write = summary[k]["WRITE_SIZE"] / summary[k]["calls"] * 1024.0
     entry[key + "_bytes_per_launch"] = fetch + write
