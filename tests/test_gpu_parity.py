@@ -78,8 +78,10 @@ def test_affinity_degree_laplacian(ctx, golden, png, name):
     ctx.destroy(K_A, L_A, L_A2, K_B)
 
 
+@pytest.mark.parametrize("paths", ["direct", "grid"])
 @pytest.mark.parametrize("kernel,ok", [(glf.KERNEL_PHOTOMETRIC, orc.PHOTOMETRIC), (glf.KERNEL_SPATIAL, orc.SPATIAL)])
-def test_other_kernels_against_golden(ctx, golden, kernel, ok):
+def test_other_kernels_against_golden(ctx, golden, kernel, ok, paths, monkeypatch):
+    monkeypatch.setenv("GLF_DEG_PATH", paths)   # the degree in both forms (one factor of the kernel is constant here)
     g = golden("syn32.npz")
     name = "photometric" if kernel == glf.KERNEL_PHOTOMETRIC else "spatial"
     d_img = ctx.to_device(g["img"])
@@ -354,6 +356,30 @@ def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, m
     if info["outer_its"] == ref["outer_its"]:
         assert psnr(out.cpu().numpy(), out_ref) >= 50.0
         assert np.linalg.norm(zf.cpu().numpy() - zf_ref) / np.linalg.norm(zf_ref) <= 1e-4
+
+
+@pytest.mark.parametrize("paths", ["direct", "grid"])
+@pytest.mark.parametrize("kernel,ok", [(glf.KERNEL_PHOTOMETRIC, orc.PHOTOMETRIC), (glf.KERNEL_SPATIAL, orc.SPATIAL)])
+def test_end_to_end_other_kernels(ctx, kernel, ok, paths, monkeypatch):
+    """Photometric-only and spatial-only kernels (hpc/affinity.c:8-57) through the whole path in both kernel families:
+    one of the three factors of the grid forms is identically 1, and nothing underflows to zero for the photometric one."""
+    for k in ("GLF_NYS_PATH", "GLF_DEG_PATH"):
+        monkeypatch.setenv(k, paths)
+    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    img = glf.synth_image(128, 96, seed=13)
+    prm = orc.default_params(ok)
+    prm.h_loc, prm.h_val = 25.0, 35.0
+    zf_ref, out_ref, ref = orc.image_processing(img, 160, 12, epsilon=0.05, inner_rtol=1e-5, seed=1, prm=prm)
+    opt = glf.default_options(num_samples=160, num_eigvals=12, epsilon=0.05)
+    opt.kernel, opt.h_loc, opt.h_val = kernel, 25.0, 35.0
+    for skip in (0, 1):
+        opt.skip_exact_zeros = skip
+        out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+        assert info["alpha"] == pytest.approx(ref["alpha"], rel=2e-6)
+        assert abs(info["outer_its"] - ref["outer_its"]) <= 1
+        if info["outer_its"] == ref["outer_its"]:
+            assert np.linalg.norm(zf.cpu().numpy() - zf_ref) / np.linalg.norm(zf_ref) <= 1e-4
+            assert psnr(out.cpu().numpy(), out_ref) >= 50.0
 
 
 def test_barbara_config2(ctx, golden, png):
