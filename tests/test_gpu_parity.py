@@ -582,3 +582,19 @@ def test_grid_forms_with_many_grid_rows_or_columns(ctx, w, h, ns, monkeypatch):
     assert a[1]["outer_its"] == b[1]["outer_its"]
     rel = float(torch.linalg.norm(a[0].double() - b[0].double()) / torch.linalg.norm(b[0].double()))
     assert rel < 1e-6
+
+
+def test_run_to_run_bitwise_reproducible(ctx):
+    """Every reduction runs in a fixed order (no atomics): the same input gives the same bits, run after run
+    (1280 x 1024: wide enough for the grid-factored forms to be chosen automatically)."""
+    import torch
+    d_img = ctx.to_device(glf.synth_image(1280, 1024, seed=3))
+    opt = glf.default_options(num_samples=6553, num_eigvals=32, epsilon=0.1)
+    runs = []
+    for _ in range(3):
+        out, zf, info = ctx.image_processing(d_img, opt, want_float=True)
+        runs.append((out.clone(), zf.clone(), info["alpha"], info["eigvals"].copy()))
+    for out, zf, alpha, lam in runs[1:]:
+        assert torch.equal(out, runs[0][0]) and torch.equal(zf.view(torch.int32), runs[0][1].view(torch.int32))
+        assert alpha == runs[0][2]
+        np.testing.assert_array_equal(lam, runs[0][3])
