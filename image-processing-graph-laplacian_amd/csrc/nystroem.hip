@@ -396,19 +396,46 @@ __global__ void k_samples_soa(const float4 *__restrict__ samples, unsigned p_pad
     o[192] = __int_as_float(128 * (int)v.z); // value * (32 banks * 4 B): row stride of the LUT kernel's photometric table
 }
 
-__global__ void k_col_absmax(const float *__restrict__ psi, unsigned p, unsigned ld, float *__restrict__ out)
+// out[c] = max_i |psi[i][c]|: coalesced row reads, 128 rows per workgroup, then one workgroup over the block maxima
+constexpr int CAM_ROWS = 128;
+__global__ __launch_bounds__(256) void k_col_absmax_part(const float *__restrict__ psi, unsigned p, unsigned ld,
+                                                          float *__restrict__ part)
 {
     __shared__ float sh[256];
-    const unsigned c = blockIdx.x;
+    const unsigned col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    const unsigned base = blockIdx.x * CAM_ROWS;
     float m = 0.f;
-    for (unsigned i = threadIdx.x; i < p; i += 256) m = fmaxf(m, fabsf(psi[(size_t)i * ld + c]));
+    for (unsigned r = rl; r < CAM_ROWS; r += nrl) {
+        const unsigned i = base + r;
+        if (i >= p) break;
+        m = fmaxf(m, fabsf(psi[(size_t)i * ld + col]));
+    }
     sh[threadIdx.x] = m;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
-        __syncthreads();
+    if (threadIdx.x < ld) {
+        for (unsigned r = 1; r < nrl; ++r) m = fmaxf(m, sh[r * ld + col]);
+        part[(size_t)blockIdx.x * ld + col] = m;
     }
-    if (threadIdx.x == 0) out[c] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_col_absmax_fin(const float *__restrict__ part, int nblk, unsigned ld, float *__restrict__ out)
+{
+    __shared__ float sh[256];
+    const unsigned col = threadIdx.x % ld, pt = threadIdx.x / ld, npt = 256 / ld;
+    float m = 0.f;
+    for (int b = (int)pt; b < nblk; b += (int)npt) m = fmaxf(m, part[(size_t)b * ld + col]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x < ld) {
+        for (unsigned r = 1; r < npt; ++r) m = fmaxf(m, sh[r * ld + col]);
+        out[col] = m;
+    }
+}
+// scratch: ceil(p / CAM_ROWS) * ld floats
+static void col_absmax(hipStream_t st, const float *psi, unsigned p, unsigned ld, float *scratch, float *out)
+{
+    const int nblk = (int)ceil_div(p, CAM_ROWS);
+    hipLaunchKernelGGL(k_col_absmax_part, dim3(nblk), dim3(256), 0, st, psi, p, ld, scratch);
+    hipLaunchKernelGGL(k_col_absmax_fin, dim3(1), dim3(256), 0, st, scratch, nblk, ld, out);
 }
 
 // |a - b| + c in one instruction (hipcc expands __usad into max/min/sub/add)
@@ -684,7 +711,9 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     GLF_TRY(invscale.alloc(ctx, LD));
     GLF_TRY(soa.alloc(ctx, (size_t)p_pad * 4));
     GLF_TRY(psi16.alloc(ctx, (size_t)p_pad * LD * 2));
-    hipLaunchKernelGGL(k_col_absmax, dim3(LD), dim3(256), 0, st, d_psi, p, LD, colmax.p);
+    DevBuf<float> camx;
+    GLF_TRY(camx.alloc(ctx, (size_t)ceil_div(p, CAM_ROWS) * LD));
+    col_absmax(st, d_psi, p, LD, camx.p, colmax.p);
     GLF_LAUNCH_CHECK(ctx);
     std::vector<float> hmax(LD), hscale(LD), hinv(LD);
     GLF_HIP(ctx, hipMemcpyAsync(hmax.data(), colmax.p, sizeof(float) * LD, hipMemcpyDeviceToHost, st));
