@@ -2,7 +2,7 @@ import sys, time, os
 sys.path.insert(0, "image-processing-graph-laplacian_amd"); sys.path.insert(0, "oracle")
 import numpy as np, torch, glf
 ctx = glf.Context(0)
-cases = [(2048, 2048, 0.005, 64), (3000, 1200, 0.004, 48)]
+cases = [(1280, 1024, 0.005, 32), (4096, 4096, 0.005, 64)]
 if len(sys.argv) > 1: cases = cases[:int(sys.argv[1])]
 for (W, H, frac, m) in cases:
     img = glf.synth_image(W, H, seed=7)
