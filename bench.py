@@ -288,7 +288,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g, "
-                                   "every K_B entry evaluated (no skipping)" % (size, size, args.sample_frac * 100, p, m, args.epsilon),
+                                   "no exact-zero skipping (every kernel entry enters the sums: %s)" % (size, size, args.sample_frac * 100, p, m, args.epsilon,
+                                   "grid-factored forms" if info["nystroem_path"] == 1 else "entry-by-entry kernels"),
                        "N": N, "p": p, "m": m, "epsilon": args.epsilon, "outer_its": info["outer_its"],
                        "inner_its_total": info["inner_its_total"], "residual": round(info["residual"], 5),
                        "contraction": "f16 split (hi+lo), f32 accumulate" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32 MFMA",
