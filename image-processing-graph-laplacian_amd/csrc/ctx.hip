@@ -90,7 +90,6 @@ int glf_ctx_destroy(glf_ctx *ctx)
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->x0_block) (void)hipFree(ctx->x0_block);
     glf::pool_free_all(ctx, false);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GLF_OK;

@@ -26,7 +26,6 @@ struct glf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    hipStream_t aux_stream = nullptr; // second stream for the column pass overlapping the next row pass (created on first use)
     glf_comm comm{};
     bool has_comm = false;
     char last_error[512] = {0};
