@@ -951,7 +951,7 @@ __global__ void k_scale_all(float *__restrict__ X, unsigned n, unsigned ld, unsi
 // coefficients are f64 throughout). The recurrence loses digits as cond(V)^2 eps_f64: if any q_k falls below
 // GSF_COND_FLOOR * G_kk (vectors dependent to ~5 digits) the device raises a flag, X is left untouched and the
 // caller runs the column-by-column sweep instead.
-constexpr int GSF_ROWS = 512;            // rows per Gram workgroup
+constexpr int GSF_ROWS = 128;            // rows per Gram workgroup (667 workgroups at p = 85 264)
 constexpr double GSF_COND_FLOOR = 1e-10; // q_k / G_kk below this: fall back to the sequential sweep
 
 // Gpart[chunk][a][b] = sum_{i in chunk} X[i][a] X[i][b] for the tiles on and above the diagonal; 16 x 16 threads, each an
@@ -993,18 +993,26 @@ __global__ __launch_bounds__(256) void k_gsf_gram(const float *__restrict__ X, u
         for (int v = 0; v < E; ++v) out[(size_t)(ca + u) * ld + cb + v] = acc[u][v];
 }
 
-// G = sum over chunks (fixed order), mirrored into the tiles below the diagonal
+// G = sum over chunks (fixed order: four interleaved partial sums per entry, combined through LDS), mirrored into the
+// tiles below the diagonal; 64 entries per workgroup
 __global__ __launch_bounds__(256) void k_gsf_sum(const double *__restrict__ Gpart, int nchunks, unsigned ld, int tile,
                                                   double *__restrict__ G)
 {
-    const unsigned e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= ld * ld) return;
+    __shared__ double sh[256];
+    const unsigned e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
     const unsigned a = e / ld, b = e % ld;
-    if (b / tile < a / tile) return;
+    const bool live = e < ld * ld && b / tile >= a / tile;
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += Gpart[(size_t)c * ld * ld + e];
-    G[e] = s;
-    if (b / tile > a / tile) G[(size_t)b * ld + a] = s;
+    if (live)
+        for (int c = part; c < nchunks; c += 4) s += Gpart[(size_t)c * ld * ld + e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && live) {
+        const double tot = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
+        G[e] = tot;
+        if (b / tile > a / tile) G[(size_t)b * ld + a] = tot;
+    }
 }
 
 // One workgroup. S (ld x ld, f64, LDS for ld <= 64, else global) starts as G and is reduced in place:
@@ -1163,7 +1171,7 @@ static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, unsi
         hipLaunchKernelGGL((k_gsf_gram<64>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
     else
         hipLaunchKernelGGL((k_gsf_gram<32>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
-    hipLaunchKernelGGL(k_gsf_sum, dim3((ld * ld + 255) / 256), dim3(256), 0, st, f.Gpart.p, f.nchunks, ld, tile, f.G.p);
+    hipLaunchKernelGGL(k_gsf_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, f.Gpart.p, f.nchunks, ld, tile, f.G.p);
     if (ld <= 64)
         hipLaunchKernelGGL(k_gsf_recur_lds, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.Tn.p, d_norms, f.flag.p);
     else
