@@ -221,9 +221,9 @@ def main():
             # every f32-equivalent multiply-add is three f16 MFMA products (hi*hi + hi*lo + lo*hi)
             nys_peak = PEAK_F16_MFMA_TFLOPS
             if grid_path:
-                nys_kernel = ("k_grid_rowpass<%d> + k_grid_colpass<%d> (grid-factored Nystroem contraction: "
-                              "T[r][v][b] = sum_a P Er Psi on v_mfma_f32_32x32x16_f16 with both operands split into f16 hi+lo "
-                              "pairs, then Phi = sum_b Ec T in f32 FMAs)" % (ld // 32, ld // 32))
+                nys_kernel = ("k_grid_rowpass_rt<%d> + k_grid_colpass<%d> (grid-factored Nystroem contraction: "
+                              "T[r][v][b] = sum_a Er (P Psi) on v_mfma_f32_32x32x16_f16 with both operands split into f16 hi+lo "
+                              "pairs, then Phi = sum_b Ec T the same way)" % (ld // 32, ld // 32))
             else:
                 nys_kernel = ("k_nystroem_f16s<%d,%d> (direct Nystroem contraction; K_B generated in registers%s, split-f16 MFMA)"
                               % (ld // 32, 2 if ld <= 64 else 1,
@@ -254,15 +254,16 @@ def main():
                   "launches_per_step": mvs["launches"] / args.steps, "avg_ms": round(mv_avg_ms, 4),
                   "ms_per_step": round(mvs["ms"] / args.steps, 3)}
         if info["matvec_path"] == 1 and rps["launches"] > 0:
-            # dominant kernel: k_grid_rowpass (the inner sums of the Nystroem contraction and of every L_A sweep)
+            # dominant kernel: the row pass of the Nystroem contraction (k_grid_rowpass_rt; by name the largest share of the step)
             rp_avg_ms = rps["ms"] / rps["launches"]
             rp_flops = rps["flops"] / rps["launches"]
             rp_tflops = rp_flops / (rp_avg_ms * 1e-3) / 1e12
             rp_peak = PEAK_F16_MFMA_TFLOPS / 3.0
             roofline = {
-                "kernel": "k_grid_rowpass<%d> (T[r][v][b] = sum_a P(|v - v_ab|) Er(r - R_a) Psi[(a,b)]: GEMM per sample column b on "
-                          "v_mfma_f32_32x32x16_f16, both operands split into f16 hi+lo, f32 accumulate; timed here on the launches of "
-                          "the Nystroem stage, the L_A sweeps of the eigensolver run the same kernel on the grid rows)" % (min(ld, 64) // 32),
+                "kernel": "k_grid_rowpass_rt<%d> (T[r][v][b] = sum_a Er(r - R_a) (P(|v - v_ab|) Psi[(a,b)]): per (sample column b, "
+                          "value v) a GEMM [rows x grid rows] x [grid rows x m] on v_mfma_f32_32x32x16_f16, both operands split into "
+                          "f16 hi+lo, f32 accumulate; the launches of the Nystroem stage -- the L_A sweeps of the eigensolver compute "
+                          "the same sums over the grid rows with k_grid_rowpass)" % (min(ld, 64) // 32),
                 "bound": "mfma", "achieved": round(rp_tflops, 1), "peak": round(rp_peak, 1), "unit": "TFLOP/s",
                 "frac": round(rp_tflops / rp_peak, 4), "traffic": prof.get("grid_rowpass_bytes_per_launch"),
                 "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add",

@@ -228,22 +228,24 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
     phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
     Pi_inv = ctx.InverseDiagMat(Pi)
     got = {}
-    for mode, env in (("grid", {"GLF_NYS_PATH": "grid"}), ("lut", {"GLF_NYS_PATH": "direct"}),
-                      ("exp", {"GLF_NYS_PATH": "direct", "GLF_NYS_NO_LUT": "1"})):
-        for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT"):
+    for mode, env in (("grid", {"GLF_NYS_PATH": "grid"}), ("grid_v1", {"GLF_NYS_PATH": "grid", "GLF_ROWPASS": "v1"}),
+                      ("lut", {"GLF_NYS_PATH": "direct"}), ("exp", {"GLF_NYS_PATH": "direct", "GLF_NYS_NO_LUT": "1"})):
+        for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT", "GLF_ROWPASS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         phi = ctx.Nystroem(L_B, phi_A, Pi_inv)
         got[mode] = ctx.mat_to_numpy(phi)
         ctx.destroy(phi)
-    for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT"):
+    for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT", "GLF_ROWPASS"):
         monkeypatch.delenv(k, raising=False)
     scale = np.abs(ref).max()
     for mode in got:
         np.testing.assert_allclose(got[mode], ref, rtol=0, atol=2e-4 * scale, err_msg=mode)
     np.testing.assert_allclose(got["lut"], got["exp"], rtol=0, atol=2e-5 * scale)
     np.testing.assert_allclose(got["grid"], got["exp"], rtol=0, atol=2e-5 * scale)
+    # the two row-pass kernels (row-tile form: Er as the A operand; v1: one image row per wave) split different operands
+    np.testing.assert_allclose(got["grid"], got["grid_v1"], rtol=0, atol=2e-5 * scale)
     ctx.destroy(L_A, phi_A, Pi, Pi_inv, K_B)
 
 
@@ -338,13 +340,18 @@ def test_image_processing_end_to_end(ctx, golden, png, name, ns, m, eps):
         assert np.mean(np.abs(out.astype(int) - out_ref.astype(int)) <= 1) >= 0.99
 
 
+@pytest.mark.parametrize("rowpass", ["default", "v1", "rt"])
 @pytest.mark.parametrize("name,ns,m,eps", [("ragged", 20, 5, 0.1), ("cat50", 50, 53, 0.1), ("test", 100, 16, 0.1)])
-def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, monkeypatch):
+def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, rowpass, monkeypatch):
     """The grid-factored degree and Nystroem contraction are chosen automatically from 1024-pixel-wide images on;
-    forced here on the small reference images (odd widths, m up to p - 1) against the fp64 oracle."""
+    forced here on the small reference images (odd widths, m up to p - 1) against the fp64 oracle. rowpass: the default
+    choice (row-tile kernel for the Nystroem passes, k_grid_rowpass for the L_A sweeps), or one kernel for both uses."""
     monkeypatch.setenv("GLF_NYS_PATH", "grid")
     monkeypatch.setenv("GLF_DEG_PATH", "grid")
     monkeypatch.setenv("GLF_MV_PATH", "grid")
+    if rowpass != "default":
+        monkeypatch.setenv("GLF_ROWPASS", rowpass)
+        monkeypatch.setenv("GLF_ROWPASS_OP", rowpass)
     img, _ = _images(golden, png)[name]
     zf_ref, out_ref, ref = orc.image_processing(img, ns, m, epsilon=eps, inner_rtol=1e-5, seed=1)
     out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
