@@ -27,7 +27,7 @@ $(HOST)/%.o: $(HOST)/%.c include/glf.h $(HOST)/stages.h
 	gcc $(CFLAGS) -Iinclude -c $< -o $@
 
 $(PKG)/libglf.so: $(HIP_OBJS) $(CPP_OBJS) $(C_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz -pthread
 
 $(PKG)/image_processing: $(HOST)/image_processing.o $(HOST)/stages.o $(PKG)/libglf.so
 	gcc -o $@ $(HOST)/image_processing.o $(HOST)/stages.o -L$(PKG) -lglf -Wl,-rpath,'$$ORIGIN' -lm

@@ -46,6 +46,11 @@ def parse_args():
     ap.add_argument("--no-skip-leg", action="store_true",
                     help="do not time the extra exact-zero-skipping leg (reported beside the headline)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-batch-leg", action="store_true",
+                    help="skip the throughput-mode leg (BASELINE config 5: 64 tiles of 1024x1024 dealt to concurrent contexts)")
+    ap.add_argument("--batch-tiles", type=int, default=64)
+    ap.add_argument("--batch-tile-size", type=int, default=1024)
+    ap.add_argument("--batch-contexts", type=int, default=8)
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: one rank, but with the RCCL callbacks plugged in (cost of the N > 1 plumbing)")
     return ap.parse_args()
@@ -130,6 +135,44 @@ def cpu_parity_cfg2(ctx):
     }
 
 
+def run_batch_leg(args, ctx, rank, world, barrier):
+    """BASELINE config 5: a batch of equally sized tiles (one sample grid), replicas only. The tiles are split evenly over
+    the ranks; each rank deals its share to `--batch-contexts` contexts working concurrently (glf_image_processing_batch)
+    and, for comparison, runs the same share through one context. No data-path collective; time = max over ranks."""
+    ts, total = args.batch_tile_size, args.batch_tiles
+    mine = [t for t in range(total) if t % world == rank]
+    tiles = np.stack([glf.synth_image(ts, ts, seed=1000 + t) for t in mine]) if mine else np.zeros((0, ts, ts), np.uint8)
+    d_tiles = torch.from_numpy(tiles).to(ctx.device)
+    opt = glf.default_options(num_samples=int(ts * ts * args.sample_frac), num_eigvals=args.num_eigvals, epsilon=args.epsilon)
+    ctxs = [glf.Context(ctx.device.index) for _ in range(max(1, args.batch_contexts))]
+    res = {}
+    try:
+        for label, group in (("one_context", ctxs[:1]), ("concurrent", ctxs)):
+            glf.image_processing_batch(group, d_tiles[:min(len(mine), 2 * len(group))].contiguous(), opt)   # warm-up: pools, start block
+            barrier()
+            t0 = time.perf_counter()
+            outs, infos = glf.image_processing_batch(group, d_tiles, opt)
+            barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=ctx.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            res[label] = el
+    finally:
+        for c in ctxs:
+            c.close()
+    mp = total * ts * ts * 1e-6
+    return {"workload": "%d tiles of %dx%d synthetic, %.1f%% samples (p=%d each), m=%d, eps=%g: every tile through the whole path; "
+                        "replicas only (tiles split over %d rank(s), no collective)" % (total, ts, ts, args.sample_frac * 100,
+                                                                                        infos[0]["p"] if infos else 0, args.num_eigvals,
+                                                                                        args.epsilon, world),
+            "contexts_per_gpu": len(ctxs), "value": round(mp / res["concurrent"], 2), "unit": "Mpixel/s",
+            "ms_per_tile": round(res["concurrent"] * 1e3 / max(1, total), 3),
+            "one_context_value": round(mp / res["one_context"], 2),
+            "one_context_ms_per_tile": round(res["one_context"] * 1e3 / max(1, total), 3)}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +245,10 @@ def main():
         opt_skip = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals,
                                        epsilon=args.epsilon, skip_exact_zeros=1)
         skip_leg = run_leg(opt_skip)
+
+    batch_leg = None
+    if not args.no_batch_leg:
+        batch_leg = run_batch_leg(args, ctx, rank, world, barrier)
 
     if rank == 0:
         p, m = info["p"], info["m"]
@@ -312,6 +359,8 @@ def main():
                                        "degree": round(s_info["degree_evaluated"] / dense_evals, 4)},
                 "outer_its": s_info["outer_its"],
             }
+        if batch_leg is not None:
+            line["throughput_mode"] = batch_leg
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, info, args)
         if n_gpus == 1 and not args.no_parity and "cpu_baseline" in line:

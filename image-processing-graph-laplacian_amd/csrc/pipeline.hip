@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 
 namespace glf {
 
@@ -64,6 +66,55 @@ extern "C" {
 
 // ------------------------------------------------------------------------------------------
 // Stage API
+// ------------------------------------------------------------------------------------------
+// Throughput mode: a batch of equally sized tiles (BASELINE config 5)
+// ------------------------------------------------------------------------------------------
+// Every tile goes through glf_image_processing unchanged; nctx contexts (one stream and one host thread each) work
+// concurrently and take the tiles from a shared counter, so the launch- and latency-bound stages of one tile (the
+// eigensolver at 1024 x 1024: dozens of small kernels and a host round trip per outer iteration) overlap the wide
+// kernels of the others. Replicas only: no data-path exchange between tiles, contexts must not carry a comm.
+int glf_image_processing_batch(glf_ctx *const *ctxs, int nctx, const glf_options *opt, const uint8_t *d_imgs, int width, int height,
+                               int ntiles, uint8_t *d_outs, float *d_zfs, glf_stats *stats)
+{
+    if (!ctxs || nctx < 1 || !ctxs[0]) return GLF_ERR_INVALID;
+    if (ntiles < 0 || width <= 0 || height <= 0 || (ntiles > 0 && (!d_imgs || !d_outs)))
+        return set_error(ctxs[0], GLF_ERR_INVALID, "glf_image_processing_batch: %d tiles of %dx%d", ntiles, width, height);
+    for (int c = 0; c < nctx; ++c) {
+        if (!ctxs[c]) return set_error(ctxs[0], GLF_ERR_INVALID, "glf_image_processing_batch: context %d is NULL", c);
+        if (ctxs[c]->has_comm) return set_error(ctxs[0], GLF_ERR_INVALID, "glf_image_processing_batch: context %d has a comm (tiles are replicas)", c);
+        for (int d = 0; d < c; ++d)
+            if (ctxs[d] == ctxs[c]) return set_error(ctxs[0], GLF_ERR_INVALID, "glf_image_processing_batch: context %d listed twice", c);
+    }
+    const size_t N = (size_t)width * height;
+    std::atomic<int> next{0}, status{GLF_OK}, failed{-1};
+    auto worker = [&](int c) {
+        if (hipSetDevice(ctxs[c]->device) != hipSuccess) {
+            int expected = GLF_OK;
+            if (status.compare_exchange_strong(expected, GLF_ERR_NODEVICE)) failed.store(c);
+            return;
+        }
+        for (;;) {
+            const int t = next.fetch_add(1);
+            if (t >= ntiles || status.load() != GLF_OK) break;
+            const int rc = glf_image_processing(ctxs[c], opt, d_imgs + (size_t)t * N, width, height, d_outs + (size_t)t * N,
+                                                d_zfs ? d_zfs + (size_t)t * N : nullptr, nullptr, stats ? stats + t : nullptr);
+            if (rc != GLF_OK) {
+                int expected = GLF_OK;
+                if (status.compare_exchange_strong(expected, rc)) failed.store(c);
+                break;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    const int nworkers = std::min(nctx, std::max(1, ntiles));
+    for (int c = 1; c < nworkers; ++c) threads.emplace_back(worker, c);
+    worker(0);
+    for (auto &th : threads) th.join();
+    const int rc = status.load(), fc = failed.load();
+    if (rc != GLF_OK && fc > 0) std::snprintf(ctxs[0]->last_error, sizeof(ctxs[0]->last_error), "context %d: %s", fc, ctxs[fc]->last_error);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------
 
 int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const uint8_t *d_img, int width, int height,

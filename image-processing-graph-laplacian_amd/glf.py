@@ -43,7 +43,7 @@ EXPORTS = [
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
     "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
-    "glf_options_default", "glf_image_processing", "glf_EntireComputation", "glf_read_png", "glf_write_png",
+    "glf_options_default", "glf_image_processing", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png",
 ]
 
 
@@ -480,3 +480,27 @@ class Context:
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     eigvals=lam[:st.m].copy())
         return out, zf, info
+
+
+def image_processing_batch(contexts, d_imgs, opt=None):
+    """Throughput mode (glf_image_processing_batch; BASELINE config 5): d_imgs is a device uint8 tensor
+    [tiles, H, W]; the contexts (each on its own stream, none with a comm) filter the tiles concurrently.
+    Returns (outputs [tiles, H, W] uint8, list of per-tile dicts p / m / outer_its / ms_total)."""
+    ctx0 = contexts[0]
+    torch = ctx0.torch
+    assert d_imgs.dtype == torch.uint8 and d_imgs.is_cuda and d_imgs.dim() == 3 and d_imgs.is_contiguous()
+    t, h, w = d_imgs.shape
+    opt = opt or default_options()
+    outs = torch.zeros((t, h, w), dtype=torch.uint8, device=ctx0.device)
+    torch.cuda.synchronize(ctx0.device)      # inputs and the zero fill are complete before any context's stream starts
+    stats = (Stats * max(1, t))()
+    handles = (C.c_void_p * len(contexts))(*[c._ctx for c in contexts])
+    rc = _lib.glf_image_processing_batch(handles, C.c_int(len(contexts)), C.byref(opt), C.c_void_p(d_imgs.data_ptr()),
+                                         C.c_int(w), C.c_int(h), C.c_int(t), C.c_void_p(outs.data_ptr()), None, stats)
+    ctx0._check(rc, "image_processing_batch")
+    for c in contexts:
+        c.stream.synchronize()
+    infos = [dict(p=stats[i].p, m=stats[i].m, alpha=stats[i].alpha, outer_its=stats[i].eig.outer_its,
+                  ms_total=stats[i].ms_total) for i in range(t)]
+    return outs, infos
+

@@ -275,6 +275,16 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt, const uint8_t *d_
                          int height, uint8_t *d_out, float *d_zf, double *eigvals_out,
                          glf_stats *stats);
 
+/* Throughput mode for a batch of equally sized tiles (BASELINE.json configs[4]: "batch of 64 x 1024x1024 noisy tiles
+ * sharing one sample set"; hpc/sampling.c:6-23 gives tiles of one size the same sample grid). The reference would run its
+ * main once per tile (hpc/image_processing.c:279-335); here tile t = d_imgs + t*width*height goes through
+ * glf_image_processing unchanged on one of `nctx` contexts (one stream + one host thread each, tiles dealt dynamically),
+ * so every output is bit-identical to the single-image call's. Replicas only: the contexts must not carry a comm.
+ * d_outs: uint8[ntiles*height*width]; d_zfs (optional) float[ntiles*N]; stats (optional) HOST glf_stats[ntiles].
+ * On failure returns the first failing tile's status; the message is in ctxs[0]'s last error. */
+int glf_image_processing_batch(glf_ctx *const *ctxs, int nctx, const glf_options *opt, const uint8_t *d_imgs,
+                               int width, int height, int ntiles, uint8_t *d_outs, float *d_zfs, glf_stats *stats);
+
 /* EntireComputation, hpc/image_processing.c:155-181 (-no_approx): z = clamp(y - L y) with the full N x N
  * Laplacian of ComputeEntireAffinityMatrix / ComputeEntireLaplacianMatrix / ComputeResultFromEntireLaplacian
  * (hpc/affinity.c:264-336, hpc/laplacian.c:44-65, hpc/display.c:128-149). The matrices are never stored

@@ -605,3 +605,35 @@ def test_run_to_run_bitwise_reproducible(ctx):
         assert torch.equal(out, runs[0][0]) and torch.equal(zf.view(torch.int32), runs[0][1].view(torch.int32))
         assert alpha == runs[0][2]
         np.testing.assert_array_equal(lam, runs[0][3])
+
+
+def test_batch_throughput_mode_is_bit_identical_to_single_calls(ctx):
+    """BASELINE config 5 (a batch of equally sized tiles sharing one sample set): glf_image_processing_batch deals the
+    tiles to several contexts working concurrently; every tile's output must equal the single-image call's, bit for bit
+    (here 7 tiles of 256 x 192 on 3 contexts, and the 1-context / more-contexts-than-tiles / empty-batch edges)."""
+    import torch
+    tiles = np.stack([glf.synth_image(256, 192, seed=100 + t) for t in range(7)])
+    d_tiles = torch.from_numpy(tiles).to(ctx.device)
+    opt = glf.default_options(num_samples=500, num_eigvals=16, epsilon=0.1)
+    single = []
+    for t in range(7):
+        out, _, info = ctx.image_processing(d_tiles[t], opt)
+        single.append((out.cpu().numpy(), info))
+    extra = [glf.Context(0) for _ in range(2)]
+    try:
+        for group in ([ctx] + extra, [ctx], [ctx] + extra):
+            outs, infos = glf.image_processing_batch(group, d_tiles if group is not None else d_tiles, opt)
+            outs = outs.cpu().numpy()
+            for t in range(7):
+                assert np.array_equal(outs[t], single[t][0]), "tile %d" % t
+                assert infos[t]["p"] == single[t][1]["p"] and infos[t]["outer_its"] == single[t][1]["outer_its"]
+                assert infos[t]["alpha"] == single[t][1]["alpha"]
+        outs, infos = glf.image_processing_batch([ctx] + extra, d_tiles[:2].contiguous(), opt)   # more contexts than tiles
+        assert np.array_equal(outs.cpu().numpy()[1], single[1][0])
+        outs, infos = glf.image_processing_batch([ctx] + extra, d_tiles[:0].contiguous(), opt)   # empty batch
+        assert outs.shape[0] == 0
+        with pytest.raises(glf.GlfError):                                                        # a context listed twice
+            glf.image_processing_batch([ctx, ctx], d_tiles, opt)
+    finally:
+        for c in extra:
+            c.close()
