@@ -1018,12 +1018,50 @@ __global__ __launch_bounds__(256) void k_gsf_sum(const double *__restrict__ Gpar
 // One workgroup. S (ld x ld, f64, LDS for ld <= 64, else global) starts as G and is reduced in place:
 // upper part S[j][k] <- c_jk, diagonal <- q_j, then the strictly lower part S[k][j] <- T[j][k], T = C^-1.
 // Outputs: Tn[j][k] = T[j][k] / |u_k| (upper triangular, zero elsewhere), norms[k] = |u_k| = sqrt(q_k), flag.
+// REGS (ld <= 64): the Schur complement lives in registers, element (k, l) = (t / 64 + 4 r, t % 64) in a[r] of thread t;
+// step j broadcasts its column j through a double-buffered LDS vector, so a step is one barrier and 18 LDS reads per
+// thread instead of two barriers and a read-modify-write sweep of S in LDS (the 64 steps took ~60 of the kernel's 106 us).
+template <bool REGS>
 __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double *__restrict__ G, double *__restrict__ Tn,
                                double *__restrict__ norms, int *__restrict__ flag)
 {
     const unsigned t = threadIdx.x;
     __shared__ int bad;
     if (t == 0) bad = 0;
+    if (REGS) {
+        __shared__ double colj[2][64], gdiag[64];
+        const unsigned tx = t & 63, ty = t >> 6;
+        if (t < 64) gdiag[t] = t < m ? G[(size_t)t * ld + t] : 0.0; // (a global load per step for the check below cost 1 us each)
+        double a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned k = ty + 4 * r;
+            a[r] = (k < ld && tx < ld) ? G[(size_t)k * ld + tx] : 0.0;
+        }
+        for (unsigned e = t; e < ld * ld; e += 256) S[e] = 0.0;
+        __syncthreads();
+        for (unsigned j = 0; j < m; ++j) {
+            double *cj = colj[j & 1];
+            if (tx == j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cj[ty + 4 * r] = a[r];
+            }
+            __syncthreads(); // (the buffer written two steps ago is free: every thread passed the barrier of step j - 1 since)
+            const double qj = cj[j];
+            if (t == 0 && !(qj > GSF_COND_FLOOR * gdiag[j]) && gdiag[j] > 0.0) bad = 1;
+            const double cl = (qj != 0.0 && tx > j && tx < m) ? cj[tx] / qj : 0.0; // c_j,tx (0 for a zero vector, as the sweep does)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned k = ty + 4 * r;
+                if (k > j && k < m) a[r] -= cj[k] * cl; // S[k][l] -= <v_k,u_j> c_jl, k, l > j
+            }
+            if (ty == 0) {
+                if (tx > j && tx < m) S[(size_t)j * ld + tx] = cl;
+                if (tx == j) S[(size_t)j * ld + j] = qj;
+            }
+        }
+        __syncthreads();
+    } else {
     for (unsigned e = t; e < ld * ld; e += 256) S[e] = G[e];
     __syncthreads();
     for (unsigned j = 0; j < m; ++j) {
@@ -1040,12 +1078,31 @@ __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double 
         }
         __syncthreads(); // (column j below the diagonal is read above and only overwritten by the inversion below)
     }
+    }
     // T = C^-1, column k by thread k: T[k][k] = 1, T[j][k] = -sum_{i=j+1..k} c_ji T[i][k]; stored at S[k][j] (j < k)
-    for (unsigned k = t; k < m; k += 256) {
+    // Four adjacent lanes share a column (the dot product over i is dealt to them mod 4 and summed by two shuffles), and
+    // the operands of four terms are read before they are used: the single-lane loop was a chain of ~2000 dependent LDS
+    // round trips for the last column (100 of the kernel's 170 us). A lane reads T[i][k] entries its quad's lane 0 wrote
+    // in earlier iterations: same wave, and a wave's LDS / global accesses complete in order.
+    for (unsigned k = t >> 2; k < m; k += 64) {
+        const unsigned s4 = t & 3;
         for (int j = (int)k - 1; j >= 0; --j) {
-            double acc = S[(size_t)j * ld + k]; // i = k term: c_jk * 1
-            for (unsigned i = (unsigned)j + 1; i < k; ++i) acc = fma(S[(size_t)j * ld + i], S[(size_t)k * ld + i], acc);
-            S[(size_t)k * ld + j] = -acc;
+            double acc = 0.0;
+            unsigned i = (unsigned)j + 1 + s4;
+            for (; i + 12 < k; i += 16) {
+                const double a0 = S[(size_t)j * ld + i], a1 = S[(size_t)j * ld + i + 4], a2 = S[(size_t)j * ld + i + 8],
+                             a3 = S[(size_t)j * ld + i + 12];
+                const double b0 = S[(size_t)k * ld + i], b1 = S[(size_t)k * ld + i + 4], b2 = S[(size_t)k * ld + i + 8],
+                             b3 = S[(size_t)k * ld + i + 12];
+                acc = fma(a0, b0, acc);
+                acc = fma(a1, b1, acc);
+                acc = fma(a2, b2, acc);
+                acc = fma(a3, b3, acc);
+            }
+            for (; i < k; i += 4) acc = fma(S[(size_t)j * ld + i], S[(size_t)k * ld + i], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (s4 == 0) S[(size_t)k * ld + j] = -(acc + S[(size_t)j * ld + k]); // i = k term: c_jk * 1
         }
     }
     __syncthreads();
@@ -1071,33 +1128,35 @@ __global__ __launch_bounds__(256) void k_gsf_recur_lds(unsigned ld, unsigned m, 
                                                         int *__restrict__ flag)
 {
     __shared__ double S[64 * 64];
-    gsf_recur_body(S, ld, m, G, Tn, norms, flag);
+    gsf_recur_body<true>(S, ld, m, G, Tn, norms, flag);
 }
 
 __global__ __launch_bounds__(256) void k_gsf_recur_global(unsigned ld, unsigned m, const double *__restrict__ G,
                                                            double *S, double *__restrict__ Tn, double *__restrict__ norms,
                                                            int *__restrict__ flag)
 {
-    gsf_recur_body(S, ld, m, G, Tn, norms, flag);
+    gsf_recur_body<false>(S, ld, m, G, Tn, norms, flag);
 }
 
-// X[i][k] <- sum_{j<=k} X[i][j] Tn[j][k] (f64 accumulation), in place; 8192 / ld rows per workgroup, thread = column.
+// X[i][k] <- sum_{j<=k} X[i][j] Tn[j][k] (f64 accumulation), in place; GSF_APPLY_TILE / ld rows per workgroup (32 at ld = 64:
+// with 128 the 42 workgroups of a 5329-sample block left most of the chip idle), thread = column.
+constexpr unsigned GSF_APPLY_TILE = 2048;
 __global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsigned n, unsigned ld, unsigned m,
                                                     const double *__restrict__ Tn, const int *__restrict__ flag)
 {
     if (*flag) return; // ill-conditioned: the caller runs the sequential sweep on the untouched X
-    __shared__ float xs[8192];
+    __shared__ float xs[GSF_APPLY_TILE];
     __shared__ double ts[4096];
-    const unsigned rows = 8192 / ld, jb = min(4096u / ld, ld); // rows per workgroup; T rows per staged block (Tn has ld rows)
+    const unsigned rows = GSF_APPLY_TILE / ld, jb = min(4096u / ld, ld); // rows per workgroup; T rows per staged block (Tn has ld rows)
     const unsigned r0 = blockIdx.x * rows;
-    const unsigned col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld, rpt = rows / nrl; // rpt = 32
+    const unsigned col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld, rpt = rows / nrl; // rpt = 8
     for (unsigned e = threadIdx.x; e < rows * ld; e += 256) {
         const unsigned i = r0 + e / ld;
         xs[e] = i < n ? X[(size_t)i * ld + e % ld] : 0.f;
     }
-    double acc[32];
+    double acc[8];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
     for (unsigned j0 = 0; j0 < m; j0 += jb) {
         __syncthreads();
         for (unsigned e = threadIdx.x; e < jb * ld; e += 256) ts[e] = Tn[(size_t)j0 * ld + e];
@@ -1106,13 +1165,13 @@ __global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsign
         for (unsigned j = 0; j < jn; ++j) {
             const double tv = ts[j * ld + col];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) acc[q] = fma((double)xs[(rl + q * nrl) * ld + j0 + j], tv, acc[q]);
+            for (int q = 0; q < 8; ++q) acc[q] = fma((double)xs[(rl + q * nrl) * ld + j0 + j], tv, acc[q]);
         }
     }
     (void)rpt;
     if (col < m)
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const unsigned i = r0 + rl + q * nrl;
             if (i < n) X[(size_t)i * ld + col] = (float)acc[q];
         }
@@ -1176,7 +1235,7 @@ static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, unsi
         hipLaunchKernelGGL(k_gsf_recur_lds, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.Tn.p, d_norms, f.flag.p);
     else
         hipLaunchKernelGGL(k_gsf_recur_global, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.S.p, f.Tn.p, d_norms, f.flag.p);
-    hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, 8192 / ld)), dim3(256), 0, st, X, n, ld, m, f.Tn.p, f.flag.p);
+    hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, GSF_APPLY_TILE / ld)), dim3(256), 0, st, X, n, ld, m, f.Tn.p, f.flag.p);
     GLF_LAUNCH_CHECK(ctx);
     int h_flag = 0;
     GLF_HIP(ctx, hipMemcpyAsync(&h_flag, f.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1462,7 +1521,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         if (it % opti_gs == 0) {
             GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :174-177
             if (ax_ready && gs.last_fused) // A X_new = (A Y) Tn
-                hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(p, 8192 / ld)), dim3(256), 0, st, rs.AX.p, p, ld, m,
+                hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(p, GSF_APPLY_TILE / ld)), dim3(256), 0, st, rs.AX.p, p, ld, m,
                                    gs.fused.Tn.p, gs.fused.flag.p);
             else
                 ax_ready = false; // column-by-column sweep: no triangular map at hand

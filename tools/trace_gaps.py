@@ -19,3 +19,6 @@ for s, e, n in ks:
 print("span %.2f ms busy %.2f ms idle %.2f ms" % ((last_end - t0) / 1e6, busy / 1e6, gap_total / 1e6))
 print("largest idle-before-kernel:")
 for n, g in gaps.most_common(12): print("   %-42s %8.3f ms" % (n, g / 1e6))
+print("largest kernels:")
+for n, g in sorted(per.items(), key=lambda kv: -kv[1])[:14]: print("   %-50s %8.3f ms" % (n, g / 1e6))
+print("kernel launches in the run:", len(ks))
