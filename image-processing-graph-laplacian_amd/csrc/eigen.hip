@@ -750,8 +750,10 @@ struct CgWork {
         s.alpha = scal.p + 2 * ld;
         s.beta = scal.p + 3 * ld;
         s.active = flags.p;
-        s.nactive = flags.p + ld;
+        // the convergence counter is written by the kernels straight into pinned host memory (device-visible, coherent):
+        // a stream synchronise then suffices -- the 4-byte D2H copy was a copy-kernel launch of its own (~20 us per check)
         GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_nactive), sizeof(int), hipHostMallocDefault));
+        s.nactive = h_nactive;
         return GLF_OK;
     }
 };
@@ -767,9 +769,8 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
     hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, m, w.s);
     GLF_LAUNCH_CHECK(ctx);
     int it = 0;
-    GLF_HIP(ctx, hipMemcpyAsync(w.h_nactive, w.s.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
     GLF_HIP(ctx, hipStreamSynchronize(st));
-    while (*w.h_nactive > 0 && it < max_it) {
+    while (*(volatile int *)w.h_nactive > 0 && it < max_it) {
         ++it;
         GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld, w.shard));
         hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p, w.AP.p, p, ld, w.partial.p);
@@ -779,7 +780,6 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
         hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, rtol * rtol, w.s);
         hipLaunchKernelGGL(k_cg_pupdate, dim3(nelem_blocks), dim3(256), 0, st, w.P.p, w.R.p, w.dinv.p, p, ld, w.s);
         GLF_LAUNCH_CHECK(ctx);
-        GLF_HIP(ctx, hipMemcpyAsync(w.h_nactive, w.s.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }
     (void)p32;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_gsf_sum(const double *__restrict__ Gpar
 // thread instead of two barriers and a read-modify-write sweep of S in LDS (the 64 steps took ~60 of the kernel's 106 us).
 template <bool REGS>
 __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double *__restrict__ G, double *__restrict__ Tn,
-                               double *__restrict__ norms, int *__restrict__ flag)
+                               double *__restrict__ norms, int *__restrict__ flag, int *__restrict__ flag_host)
 {
     const unsigned t = threadIdx.x;
     __shared__ int bad;
@@ -1120,22 +1120,25 @@ __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double 
         const double qk = S[(size_t)t * ld + t];
         norms[t] = qk > 0.0 ? sqrt(qk) : 0.0;
     }
-    if (t == 0) *flag = bad;
+    if (t == 0) {
+        *flag = bad;
+        if (flag_host) *flag_host = bad; // pinned host memory: read after a stream synchronise, no copy launch
+    }
 }
 
 __global__ __launch_bounds__(256) void k_gsf_recur_lds(unsigned ld, unsigned m, const double *__restrict__ G,
                                                         double *__restrict__ Tn, double *__restrict__ norms,
-                                                        int *__restrict__ flag)
+                                                        int *__restrict__ flag, int *__restrict__ flag_host)
 {
     __shared__ double S[64 * 64];
-    gsf_recur_body<true>(S, ld, m, G, Tn, norms, flag);
+    gsf_recur_body<true>(S, ld, m, G, Tn, norms, flag, flag_host);
 }
 
 __global__ __launch_bounds__(256) void k_gsf_recur_global(unsigned ld, unsigned m, const double *__restrict__ G,
                                                            double *S, double *__restrict__ Tn, double *__restrict__ norms,
-                                                           int *__restrict__ flag)
+                                                           int *__restrict__ flag, int *__restrict__ flag_host)
 {
-    gsf_recur_body<false>(S, ld, m, G, Tn, norms, flag);
+    gsf_recur_body<false>(S, ld, m, G, Tn, norms, flag, flag_host);
 }
 
 // X[i][k] <- sum_{j<=k} X[i][j] Tn[j][k] (f64 accumulation), in place; GSF_APPLY_TILE / ld rows per workgroup (32 at ld = 64:
@@ -1180,6 +1183,11 @@ __global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsign
 struct GsFusedWork {
     DevBuf<double> Gpart, G, S, Tn;
     DevBuf<int> flag;
+    int *h_flag = nullptr; // pinned
+    ~GsFusedWork()
+    {
+        if (h_flag) (void)hipHostFree(h_flag);
+    }
     int nchunks = 0;
     unsigned n = 0, ld = 0;
     int init(glf_ctx *ctx, unsigned n_, unsigned ld_)
@@ -1193,6 +1201,7 @@ struct GsFusedWork {
         GLF_TRY(Tn.alloc(ctx, (size_t)ld * ld));
         if (ld > 64) GLF_TRY(S.alloc(ctx, (size_t)ld * ld));
         GLF_TRY(flag.alloc(ctx, 1));
+        if (!h_flag) GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_flag), sizeof(int), hipHostMallocDefault));
         return GLF_OK;
     }
 };
@@ -1232,15 +1241,13 @@ static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, unsi
         hipLaunchKernelGGL((k_gsf_gram<32>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
     hipLaunchKernelGGL(k_gsf_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, f.Gpart.p, f.nchunks, ld, tile, f.G.p);
     if (ld <= 64)
-        hipLaunchKernelGGL(k_gsf_recur_lds, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.Tn.p, d_norms, f.flag.p);
+        hipLaunchKernelGGL(k_gsf_recur_lds, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.Tn.p, d_norms, f.flag.p, f.h_flag);
     else
-        hipLaunchKernelGGL(k_gsf_recur_global, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.S.p, f.Tn.p, d_norms, f.flag.p);
+        hipLaunchKernelGGL(k_gsf_recur_global, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.S.p, f.Tn.p, d_norms, f.flag.p, f.h_flag);
     hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, GSF_APPLY_TILE / ld)), dim3(256), 0, st, X, n, ld, m, f.Tn.p, f.flag.p);
     GLF_LAUNCH_CHECK(ctx);
-    int h_flag = 0;
-    GLF_HIP(ctx, hipMemcpyAsync(&h_flag, f.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     GLF_HIP(ctx, hipStreamSynchronize(st));
-    *fell_back = h_flag;
+    *fell_back = *(volatile int *)f.h_flag;
     return GLF_OK;
 }
 
@@ -1384,7 +1391,13 @@ __global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, cons
 
 struct ResWork {
     DevBuf<float> AX, Gpart, G;
-    DevBuf<double> partial, sums;
+    DevBuf<double> partial;
+    double *h_sums = nullptr; // pinned host memory the last reduction kernel writes into (no D2H copy launch)
+    unsigned h_sums_n = 0;
+    ~ResWork()
+    {
+        if (h_sums) (void)hipHostFree(h_sums);
+    }
     int nchunks = 0;
     const MatShard *shard = nullptr;
     int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
@@ -1398,7 +1411,12 @@ struct ResWork {
         GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
         GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
         GLF_TRY(partial.alloc(ctx, (size_t)ceil_div(p, RED_ROWS) * ld));
-        GLF_TRY(sums.alloc(ctx, ld));
+        if (h_sums_n < ld) {
+            if (h_sums) (void)hipHostFree(h_sums);
+            h_sums = nullptr;
+            GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_sums), sizeof(double) * ld, hipHostMallocDefault));
+            h_sums_n = ld;
+        }
         return GLF_OK;
     }
 };
@@ -1415,13 +1433,11 @@ static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, u
     hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X, w.AX.p, p32, ld, w.Gpart.p);
     hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
     hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X, w.AX.p, w.G.p, p, ld, m, w.partial.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, w.partial.p, nblk, (int)ld, w.sums.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, w.partial.p, nblk, (int)ld, w.h_sums);
     GLF_LAUNCH_CHECK(ctx);
-    std::vector<double> h(ld);
-    GLF_HIP(ctx, hipMemcpyAsync(h.data(), w.sums.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
     GLF_HIP(ctx, hipStreamSynchronize(st));
     double ss = 0.0;
-    for (unsigned c = 0; c < m; ++c) ss += h[c];
+    for (unsigned c = 0; c < m; ++c) ss += ((volatile double *)w.h_sums)[c];
     *h_out = std::sqrt(ss);
     return GLF_OK;
 }
