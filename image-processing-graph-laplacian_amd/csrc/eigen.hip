@@ -1029,38 +1029,58 @@ __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double 
     __shared__ int bad;
     if (t == 0) bad = 0;
     if (REGS) {
-        __shared__ double colj[2][64], gdiag[64];
+        // Thread t holds the elements (row ty + 4 r, column tx) of the Schur complement (a) and of T = C^-1 (tr). T needs no
+        // separate triangular inversion: u_k = v_k - sum_{j<k} c_jk u_j means T[:, k] = e_k - sum_{j<k} c_jk T[:, j], and
+        // column j of T is final when step j begins -- the same rank-one update as the Schur complement's, with column j of
+        // T broadcast through LDS beside column j of S (the inversion by back substitution was 40 of the kernel's 90 us).
+        __shared__ double colj[2][64], tcolj[2][64], gdiag[64];
         const unsigned tx = t & 63, ty = t >> 6;
         if (t < 64) gdiag[t] = t < m ? G[(size_t)t * ld + t] : 0.0; // (a global load per step for the check below cost 1 us each)
-        double a[16];
+        double a[16], tr[16], myq = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned k = ty + 4 * r;
             a[r] = (k < ld && tx < ld) ? G[(size_t)k * ld + tx] : 0.0;
+            tr[r] = k == tx ? 1.0 : 0.0;
         }
-        for (unsigned e = t; e < ld * ld; e += 256) S[e] = 0.0;
         __syncthreads();
         for (unsigned j = 0; j < m; ++j) {
-            double *cj = colj[j & 1];
+            double *cj = colj[j & 1], *tcj = tcolj[j & 1];
             if (tx == j) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cj[ty + 4 * r] = a[r];
+                for (int r = 0; r < 16; ++r) {
+                    cj[ty + 4 * r] = a[r];
+                    tcj[ty + 4 * r] = tr[r];
+                }
             }
-            __syncthreads(); // (the buffer written two steps ago is free: every thread passed the barrier of step j - 1 since)
+            __syncthreads(); // (the buffers written two steps ago are free: every thread passed the barrier of step j - 1 since)
             const double qj = cj[j];
+            if (tx == j) myq = qj;
             if (t == 0 && !(qj > GSF_COND_FLOOR * gdiag[j]) && gdiag[j] > 0.0) bad = 1;
             const double cl = (qj != 0.0 && tx > j && tx < m) ? cj[tx] / qj : 0.0; // c_j,tx (0 for a zero vector, as the sweep does)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned k = ty + 4 * r;
                 if (k > j && k < m) a[r] -= cj[k] * cl; // S[k][l] -= <v_k,u_j> c_jl, k, l > j
-            }
-            if (ty == 0) {
-                if (tx > j && tx < m) S[(size_t)j * ld + tx] = cl;
-                if (tx == j) S[(size_t)j * ld + j] = qj;
+                if (k <= j) tr[r] -= tcj[k] * cl;       // T[:, l] -= c_jl T[:, j] (T[k][j] = 0 below the diagonal)
             }
         }
+        // Tn[j][k] = T[j][k] / |u_k| (upper triangular, zero elsewhere; a zero norm leaves the column unscaled), norms, flag
+        const double nk = myq > 0.0 ? sqrt(myq) : 0.0, sc = nk != 0.0 ? 1.0 / nk : 1.0;
+        if (tx < ld) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned i = ty + 4 * r;
+                if (i < ld) Tn[(size_t)i * ld + tx] = (tx < m && i <= tx) ? tr[r] * sc : 0.0;
+            }
+            if (ty == 0 && tx < m) norms[tx] = nk;
+        }
         __syncthreads();
+        if (t == 0) {
+            *flag = bad;
+            if (flag_host) *flag_host = bad; // pinned host memory: read after a stream synchronise, no copy launch
+        }
+        return;
     } else {
     for (unsigned e = t; e < ld * ld; e += 256) S[e] = G[e];
     __syncthreads();
@@ -1370,7 +1390,12 @@ __global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, cons
 {
     __shared__ double sh[256];
     __shared__ float xrow[8][256];
+    __shared__ float Gs[64 * 64]; // G for ld <= 64: the inner loop read it from global memory, one dependent load per term
     const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    const bool g_lds = ld <= 64;
+    if (g_lds)
+        for (unsigned e = threadIdx.x; e < ld * ld; e += 256) Gs[e] = G[e];
+    const float *Gc = g_lds ? Gs : G;
     double v[1] = {0.0};
     const unsigned base = blockIdx.x * RED_ROWS;
     for (unsigned r0 = 0; r0 < RED_ROWS; r0 += nrl) {
@@ -1381,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, cons
         __syncthreads();
         if (ok && col < (int)m) {
             float s = Y[(size_t)i * ld + col];
-            for (unsigned a = 0; a < m; ++a) s = fmaf(-xrow[rl][a], G[(size_t)a * ld + col], s);
+            for (unsigned a = 0; a < m; ++a) s = fmaf(-xrow[rl][a], Gc[(size_t)a * ld + col], s);
             v[0] += (double)s * (double)s;
         }
         if (base + r0 + nrl > p && base + r0 >= p) break; // uniform: whole group past the end
