@@ -313,7 +313,9 @@ def main():
                           "the same sums over the grid rows with k_grid_rowpass)" % (min(ld, 64) // 32),
                 "bound": "mfma", "achieved": round(rp_tflops, 1), "peak": round(rp_peak, 1), "unit": "TFLOP/s",
                 "frac": round(rp_tflops / rp_peak, 4), "traffic": prof.get("grid_rowpass_bytes_per_launch"),
-                "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add",
+                "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add (nominal; "
+                              "tools/mfma16_probe.hip: v_mfma_f32_32x32x16_f16 sustains 1750 TFLOP/s from registers and 1670 with "
+                              "B fragments from LDS on pseudo-random operands, 2450 on all-zero operands -- power-limited)",
                 "avg_launch_ms": round(rp_avg_ms, 4), "launches_per_step": rps["launches"] / args.steps,
                 "flops_per_launch": rp_flops, "ms_per_step": round(rps["ms"] / args.steps, 3),
                 "note": "achieved = algorithmic 2 rows 256 nc nr m flop of the launch (one product per multiply-add) / mean "

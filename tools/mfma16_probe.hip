@@ -65,8 +65,38 @@ int main()
     f16x8 *g;
     float *out;
     hipMalloc(&g, 16 * 76 * 64 * 16 + (1 << 20));
-    hipMemset(g, 0, 16 * 76 * 64 * 16 + (1 << 20));
+    { // pseudo-random finite f16 operands (all-zero operands toggle nothing and flatter the power-limited rate)
+        const size_t nh = (16 * 76 * 64 * 16 + (1 << 20)) / 2;
+        unsigned short *h = (unsigned short *)malloc(nh * 2);
+        unsigned x = 12345u;
+        for (size_t i = 0; i < nh; ++i) {
+            x = x * 1664525u + 1013904223u;
+            h[i] = (unsigned short)(((x >> 16) & 0x83FFu) | 0x3400u); // +-[0.25, 0.5)
+        }
+        hipMemcpy(g, h, nh * 2, hipMemcpyHostToDevice);
+        free(h);
+    }
     hipMalloc(&out, 4096);
+    { // sustained rate: ~150 ms of back-to-back launches (power management reacts within milliseconds)
+        const int iters = 19 * 64, wgs = 2048, reps = 24;
+        const size_t lds = 19 * 8 * 1024;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int mode = 0; mode < 2; ++mode) {
+            hipEventRecord(e0);
+            for (int r = 0; r < reps; ++r) {
+                if (mode == 0) hipLaunchKernelGGL((k_probe<0, 8>), dim3(wgs), dim3(512), lds, 0, g, out, iters);
+                else hipLaunchKernelGGL((k_probe<1, 8>), dim3(wgs), dim3(512), lds, 0, g, out, iters);
+            }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double fl = (double)reps * wgs * 8 * iters * 24.0 * 32 * 32 * 16 * 2;
+            printf("sustained, %s: %d launches %8.2f ms  %8.1f TFLOP/s\n", mode ? "B from LDS per k-step" : "registers only", reps, ms, fl / ms / 1e9);
+        }
+    }
     for (int wgs : {256, 2048}) {
         run<0, 4>("registers only, 4 waves/CU", g, out, wgs);
         run<0, 8>("registers only, 8 waves/CU", g, out, wgs);
