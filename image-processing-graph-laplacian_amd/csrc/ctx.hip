@@ -89,6 +89,7 @@ int glf_ctx_destroy(glf_ctx *ctx)
             if (e) (void)hipEventDestroy(e);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->x0_block) (void)hipFree(ctx->x0_block);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     glf::pool_free_all(ctx, false);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

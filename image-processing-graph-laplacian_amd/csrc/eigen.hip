@@ -725,11 +725,7 @@ struct CgWork {
     DevBuf<int> flags;
     CgScalars s{};
     int nblk = 0;
-    int *h_nactive = nullptr; // pinned
-    ~CgWork()
-    {
-        if (h_nactive) (void)hipHostFree(h_nactive);
-    }
+    int *h_nactive = nullptr; // in the context's pinned page
     const MatShard *shard = nullptr;
     int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
     {
@@ -752,7 +748,8 @@ struct CgWork {
         s.active = flags.p;
         // the convergence counter is written by the kernels straight into pinned host memory (device-visible, coherent):
         // a stream synchronise then suffices -- the 4-byte D2H copy was a copy-kernel launch of its own (~20 us per check)
-        GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_nactive), sizeof(int), hipHostMallocDefault));
+        if (!ctx_pinned(ctx)) return set_error(ctx, GLF_ERR_NOMEM, "pinned host page");
+        h_nactive = reinterpret_cast<int *>(ctx_pinned(ctx) + PINNED_NACTIVE);
         s.nactive = h_nactive;
         return GLF_OK;
     }
@@ -1203,11 +1200,7 @@ __global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsign
 struct GsFusedWork {
     DevBuf<double> Gpart, G, S, Tn;
     DevBuf<int> flag;
-    int *h_flag = nullptr; // pinned
-    ~GsFusedWork()
-    {
-        if (h_flag) (void)hipHostFree(h_flag);
-    }
+    int *h_flag = nullptr; // in the context's pinned page
     int nchunks = 0;
     unsigned n = 0, ld = 0;
     int init(glf_ctx *ctx, unsigned n_, unsigned ld_)
@@ -1221,7 +1214,8 @@ struct GsFusedWork {
         GLF_TRY(Tn.alloc(ctx, (size_t)ld * ld));
         if (ld > 64) GLF_TRY(S.alloc(ctx, (size_t)ld * ld));
         GLF_TRY(flag.alloc(ctx, 1));
-        if (!h_flag) GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_flag), sizeof(int), hipHostMallocDefault));
+        if (!ctx_pinned(ctx)) return set_error(ctx, GLF_ERR_NOMEM, "pinned host page");
+        h_flag = reinterpret_cast<int *>(ctx_pinned(ctx) + PINNED_GSFLAG);
         return GLF_OK;
     }
 };
@@ -1417,12 +1411,7 @@ __global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, cons
 struct ResWork {
     DevBuf<float> AX, Gpart, G;
     DevBuf<double> partial;
-    double *h_sums = nullptr; // pinned host memory the last reduction kernel writes into (no D2H copy launch)
-    unsigned h_sums_n = 0;
-    ~ResWork()
-    {
-        if (h_sums) (void)hipHostFree(h_sums);
-    }
+    double *h_sums = nullptr; // in the context's pinned page: the last reduction kernel writes into it (no D2H copy launch)
     int nchunks = 0;
     const MatShard *shard = nullptr;
     int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
@@ -1436,12 +1425,8 @@ struct ResWork {
         GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
         GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
         GLF_TRY(partial.alloc(ctx, (size_t)ceil_div(p, RED_ROWS) * ld));
-        if (h_sums_n < ld) {
-            if (h_sums) (void)hipHostFree(h_sums);
-            h_sums = nullptr;
-            GLF_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&h_sums), sizeof(double) * ld, hipHostMallocDefault));
-            h_sums_n = ld;
-        }
+        if (!ctx_pinned(ctx) || ld > 256) return set_error(ctx, GLF_ERR_NOMEM, "pinned host page");
+        h_sums = reinterpret_cast<double *>(ctx_pinned(ctx) + PINNED_SUMS);
         return GLF_OK;
     }
 };

@@ -46,6 +46,9 @@ struct glf_ctx {
     unsigned x0_p = 0, x0_m = 0, x0_ld = 0;
     unsigned long long x0_seed = 0;
     int contraction = GLF_CONTRACT_F16_SPLIT; // how glf_Nystroem / glf_image_processing contract K_B^T Psi
+    // one page of pinned, device-visible host memory the eigensolver's kernels write their flags and norms into (read
+    // after a stream synchronise; no D2H copy launches, and no hipHostMalloc per image): see glf::ctx_pinned()
+    void *pinned = nullptr;
 };
 
 namespace glf {
@@ -53,6 +56,15 @@ namespace glf {
 constexpr int WAVE = 64;
 constexpr int VEC_PAD = 64; // rows of vector blocks / lda of L_A are padded to a multiple of this (zeros)
 constexpr int NYS_PAD = 64; // sample table and Psi are zero-padded to a multiple of this many rows
+
+// pinned page layout (bytes): [0] PCG active-column counter (int), [64] Gram-Schmidt fallback flag (int),
+// [128 .. 128 + 8 * 256) residual column sums (double[ld <= 256])
+constexpr size_t PINNED_BYTES = 4096, PINNED_NACTIVE = 0, PINNED_GSFLAG = 64, PINNED_SUMS = 128;
+inline char *ctx_pinned(glf_ctx *ctx)
+{
+    if (!ctx->pinned && hipHostMalloc(&ctx->pinned, PINNED_BYTES, hipHostMallocDefault) != hipSuccess) ctx->pinned = nullptr;
+    return static_cast<char *>(ctx->pinned);
+}
 
 inline int set_error(glf_ctx *ctx, int status, const char *fmt, ...)
 {
