@@ -422,7 +422,15 @@ __global__ __launch_bounds__(256) void k_col_absmax_fin(const float *__restrict_
     __shared__ float sh[256];
     const unsigned col = threadIdx.x % ld, pt = threadIdx.x / ld, npt = 256 / ld;
     float m = 0.f;
-    for (int b = (int)pt; b < nblk; b += (int)npt) m = fmaxf(m, part[(size_t)b * ld + col]);
+    int b = (int)pt;
+    for (; b + 7 * (int)npt < nblk; b += 8 * (int)npt) { // eight loads in flight at a time
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = part[(size_t)(b + u * (int)npt) * ld + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, x[u]);
+    }
+    for (; b < nblk; b += (int)npt) m = fmaxf(m, part[(size_t)b * ld + col]);
     sh[threadIdx.x] = m;
     __syncthreads();
     if (threadIdx.x < ld) {
