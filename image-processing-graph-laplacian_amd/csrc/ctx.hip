@@ -73,8 +73,15 @@ int glf_ctx_create(glf_ctx **out, int device, void *hip_stream)
         else if (std::strcmp(mode, "f16s") == 0) ctx->contraction = GLF_CONTRACT_F16_SPLIT;
         else fprintf(stderr, "glf: ignoring GLF_CONTRACTION=%s (expected f32 or f16s)\n", mode);
     }
+    if (const char *dbg = std::getenv("GLF_POOL_DEBUG")) ctx->pool_debug = dbg[0] && dbg[0] != '0';
     *out = ctx;
     return GLF_OK;
+}
+
+int glf_ctx_debug_violations(const glf_ctx *ctx)
+{
+    if (!ctx || !ctx->pool_debug) return -1;
+    return ctx->pool_violations;
 }
 
 int glf_ctx_destroy(glf_ctx *ctx)
@@ -142,7 +149,7 @@ int glf_malloc(glf_ctx *ctx, void **dptr, size_t bytes)
     if (!ctx || !dptr) return GLF_ERR_INVALID;
     *dptr = nullptr;
     if (bytes == 0) return GLF_OK;
-    GLF_HIP(ctx, hipSetDevice(ctx->device));
+    GLF_ENTER(ctx);
     GLF_HIP(ctx, hipMalloc(dptr, bytes));
     return GLF_OK;
 }
@@ -150,6 +157,7 @@ int glf_malloc(glf_ctx *ctx, void **dptr, size_t bytes)
 int glf_free(glf_ctx *ctx, void *dptr)
 {
     if (!ctx) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     if (dptr) GLF_HIP(ctx, hipFree(dptr));
     return GLF_OK;
 }
@@ -157,6 +165,7 @@ int glf_free(glf_ctx *ctx, void *dptr)
 int glf_memcpy_h2d(glf_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     GLF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;
@@ -165,6 +174,7 @@ int glf_memcpy_h2d(glf_ctx *ctx, void *dst, const void *src, size_t bytes)
 int glf_memcpy_d2h(glf_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     GLF_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;
@@ -173,6 +183,7 @@ int glf_memcpy_d2h(glf_ctx *ctx, void *dst, const void *src, size_t bytes)
 int glf_memset(glf_ctx *ctx, void *dst, int value, size_t bytes)
 {
     if (!ctx || (bytes && !dst)) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     GLF_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return GLF_OK;
 }
@@ -212,6 +223,7 @@ int glf_mat_create_diag(glf_ctx *ctx, glf_mat *mat, int64_t n)
 int glf_mat_destroy(glf_ctx *ctx, glf_mat *mat)
 {
     if (!ctx || !mat) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     if (mat->owns_data && mat->data) (void)hipFree(mat->data);
     if (mat->owns_desc) {
         if (mat->samples) (void)hipFree(const_cast<float *>(mat->samples));
@@ -226,6 +238,7 @@ int glf_mat_destroy(glf_ctx *ctx, glf_mat *mat)
 int glf_mat_get_column(glf_ctx *ctx, const glf_mat *mat, int64_t col, float *host_out)
 {
     if (!ctx || !mat || !host_out || mat->kind != GLF_MAT_DENSE || col < 0 || col >= mat->cols) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     GLF_HIP(ctx, hipMemcpy2DAsync(host_out, sizeof(float), mat->data + col, sizeof(float) * (size_t)mat->ld, sizeof(float),
                                   (size_t)mat->rows, hipMemcpyDeviceToHost, ctx->stream));
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -259,9 +272,45 @@ void glf_host_free(void *ptr) { std::free(ptr); }
 
 namespace glf {
 
-void *pool_get(glf_ctx *ctx, size_t bytes)
+// debug pool: the guard zone of a block (POOL_GUARD_BYTES of POOL_CANARY after its usable bytes) must be intact
+static void pool_check_guard(glf_ctx *ctx, const glf_pool_block &b, const char *when)
 {
+    unsigned char h[POOL_GUARD_BYTES];
+    (void)hipStreamSynchronize(ctx->stream);
+    if (hipMemcpy(h, static_cast<char *>(b.p) + b.bytes, POOL_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < POOL_GUARD_BYTES; ++i)
+        if (h[i] != (unsigned char)POOL_CANARY) {
+            if (!bad) first = i;
+            ++bad;
+        }
+    if (bad) {
+        ++ctx->pool_violations;
+        fprintf(stderr, "glf debug pool: %zu guard bytes overwritten after a %zu-byte work buffer (first at +%zu) %s\n", bad, b.bytes,
+                b.bytes + first, when);
+        set_error(ctx, GLF_ERR_HIP, "debug pool: write past the end of a %zu-byte work buffer", b.bytes);
+    }
+}
+
+void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan)
+{
+    (void)hipSetDevice(ctx->device);
     const size_t need = (size_t)round_up((int64_t)bytes, 256);
+    if (ctx->pool_debug) { // exact size + guard zone, never reused, no stale contents
+        void *p = nullptr;
+        if (hipMalloc(&p, need + POOL_GUARD_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error(ctx, GLF_ERR_NOMEM, "hipMalloc(%zu bytes, debug pool)", need + POOL_GUARD_BYTES);
+            return nullptr;
+        }
+        (void)hipMemsetAsync(p, poison_nan ? 0xFF : 0x00, need, ctx->stream); // 0xFF...: NaN as f16, f32 and f64
+        (void)hipMemsetAsync(static_cast<char *>(p) + need, POOL_CANARY, POOL_GUARD_BYTES, ctx->stream);
+        ctx->pool.push_back(glf_pool_block{p, need, true});
+        return p;
+    }
     int best = -1;
     for (int i = 0; i < (int)ctx->pool.size(); ++i) {
         const glf_pool_block &b = ctx->pool[i];
@@ -292,11 +341,18 @@ void *pool_get(glf_ctx *ctx, size_t bytes)
 void pool_put(glf_ctx *ctx, void *ptr)
 {
     if (!ctx || !ptr) return;
-    for (auto &b : ctx->pool)
-        if (b.p == ptr) {
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+        glf_pool_block &b = ctx->pool[i];
+        if (b.p != ptr) continue;
+        if (ctx->pool_debug) { // verify the guard, then give the block back to the driver (no reuse)
+            pool_check_guard(ctx, b, "(at release)");
+            (void)hipFree(b.p);
+            ctx->pool.erase(ctx->pool.begin() + (long)i);
+        } else {
             b.in_use = false;
-            return;
         }
+        return;
+    }
     (void)hipFree(ptr); // not ours: plain allocation
 }
 
@@ -304,6 +360,7 @@ void pool_forget(glf_ctx *ctx, void *ptr)
 {
     for (size_t i = 0; i < ctx->pool.size(); ++i)
         if (ctx->pool[i].p == ptr) {
+            if (ctx->pool_debug) pool_check_guard(ctx, ctx->pool[i], "(ownership handed to the caller)");
             ctx->pool.erase(ctx->pool.begin() + (long)i);
             return;
         }
@@ -314,7 +371,10 @@ void pool_free_all(glf_ctx *ctx, bool only_unused)
     std::vector<glf_pool_block> keep;
     for (auto &b : ctx->pool) {
         if (only_unused && b.in_use) keep.push_back(b);
-        else (void)hipFree(b.p);
+        else {
+            if (ctx->pool_debug) pool_check_guard(ctx, b, "(at context teardown)");
+            (void)hipFree(b.p);
+        }
     }
     ctx->pool.swap(keep);
 }

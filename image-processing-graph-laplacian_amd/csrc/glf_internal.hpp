@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/glf.h"
@@ -17,7 +18,7 @@
 // sporadic 1.7 s stalls (driver unmap of a 29 GB block) and a device-wide sync per hipFree.
 struct glf_pool_block {
     void *p;
-    size_t bytes;
+    size_t bytes;     // usable bytes (debug pool: the exact request rounded up to 256; a guard zone follows)
     bool in_use;
 };
 
@@ -49,6 +50,9 @@ struct glf_ctx {
     // one page of pinned, device-visible host memory the eigensolver's kernels write their flags and norms into (read
     // after a stream synchronise; no D2H copy launches, and no hipHostMalloc per image): see glf::ctx_pinned()
     void *pinned = nullptr;
+    // debug pool (GLF_POOL_DEBUG=1): exact-size blocks + guard zone, NaN-filled floating-point buffers, no reuse
+    bool pool_debug = false;
+    int pool_violations = 0;
 };
 
 namespace glf {
@@ -92,6 +96,9 @@ inline int set_error(glf_ctx *ctx, int status, const char *fmt, ...)
     } while (0)
 
 #define GLF_LAUNCH_CHECK(ctx) GLF_HIP(ctx, hipGetLastError())
+// every public entry point: the calling thread's current device becomes the context's (two contexts on different GPUs in
+// one process, or one host thread per GPU in glf_multi_*, would otherwise allocate and launch on the wrong device)
+#define GLF_ENTER(ctx) GLF_HIP(ctx, hipSetDevice((ctx)->device))
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 inline int64_t ceil_div(int64_t x, int64_t q) { return (x + q - 1) / q; }
@@ -100,7 +107,10 @@ inline int64_t ceil_div(int64_t x, int64_t q) { return (x + q - 1) / q; }
 inline unsigned ld_for(unsigned m) { unsigned ld = 32; while (ld < m) ld <<= 1; return ld; }
 inline bool valid_ld(unsigned ld) { return ld == 32 || ld == 64 || ld == 128 || ld == 256; }
 
-void *pool_get(glf_ctx *ctx, size_t bytes);          // nullptr on failure (last_error set)
+constexpr size_t POOL_GUARD_BYTES = 4096;            // debug pool: canary bytes after every block
+constexpr int POOL_CANARY = 0xA5;
+// poison: the block holds floating-point data (debug pool: handed out filled with NaN; integer blocks with zeros)
+void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan = false); // nullptr on failure (last_error set)
 void pool_put(glf_ctx *ctx, void *ptr);              // back to the pool
 void pool_forget(glf_ctx *ctx, void *ptr);           // ownership leaves the pool (caller hipFree's it)
 void pool_free_all(glf_ctx *ctx, bool only_unused);
@@ -121,7 +131,8 @@ struct DevBuf {
         n = count;
         owner = ctx;
         if (count == 0) return GLF_OK;
-        p = static_cast<T *>(pool_get(ctx, count * sizeof(T)));
+        p = static_cast<T *>(pool_get(ctx, count * sizeof(T), std::is_floating_point<T>::value || std::is_same<T, _Float16>::value ||
+                                                                  std::is_same<T, float4>::value));
         return p ? GLF_OK : GLF_ERR_NOMEM;
     }
     void release()

@@ -48,7 +48,9 @@ extern "C" {
 // division; the last image row and column are never sampled.
 int glf_Sampling(int width, int height, unsigned *sample_size, unsigned **sample_indices)
 {
-    if (!sample_size || !sample_indices || width <= 0 || height <= 0 || *sample_size == 0)
+    // width or height 1: `r < h - 1u` would wrap (the reference's loop bound `i < height - 1`, hpc/sampling.c:16-18, admits no
+    // row either: no sample exists) -- rejected instead of counting forever
+    if (!sample_size || !sample_indices || width < 2 || height < 2 || *sample_size == 0)
         return GLF_ERR_INVALID;
     const unsigned w = (unsigned)width, h = (unsigned)height;
     const unsigned pitch = (unsigned)std::sqrt((double)((w * h) / *sample_size));

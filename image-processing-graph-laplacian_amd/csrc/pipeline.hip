@@ -123,6 +123,7 @@ int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const 
 {
     if (!ctx || !K_B || !d_img || width <= 0 || height <= 0) return GLF_ERR_INVALID;
     if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
+    GLF_ENTER(ctx);
     const unsigned p = sample_size;
     SampleTables tb;
     GLF_TRY(build_sample_tables(ctx, d_img, width, height, p, sample_indices, tb));
@@ -163,6 +164,7 @@ int glf_ComputeLaplacianMatrix(glf_ctx *ctx, glf_mat *L_A, glf_mat *L_B, const g
                                double *alpha_out)
 {
     if (!ctx || !L_A || !K_B || K_B->kind != GLF_MAT_KERNEL_B || !K_B->degree) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     const unsigned p = K_B->p;
     if (K_A && (K_A->kind != GLF_MAT_DENSE || K_A->rows != p || K_A->cols != p))
         return set_error(ctx, GLF_ERR_INVALID, "K_A must be dense p x p");
@@ -193,6 +195,7 @@ int glf_InversePowerIteration(glf_ctx *ctx, const glf_mat *A, unsigned m, glf_ma
                               glf_eig_stats *stats)
 {
     if (!ctx || !A || A->kind != GLF_MAT_DENSE || A->rows != A->cols) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     const unsigned p = (unsigned)A->rows;
     if (m == 0 || m >= p) return set_error(ctx, GLF_ERR_INVALID, "need 0 < m < p (m=%u p=%u)", m, p);
     if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "m = %u > 256 eigenpairs not supported", m);
@@ -223,18 +226,21 @@ int glf_InversePowerIteration(glf_ctx *ctx, const glf_mat *A, unsigned m, glf_ma
 int glf_OrthonormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms)
 {
     if (!ctx || !X || X->kind != GLF_MAT_DENSE) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     return orthonormalise(ctx, X->data, (unsigned)X->rows, (unsigned)X->cols, (unsigned)X->ld, norms);
 }
 
 int glf_NormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms)
 {
     if (!ctx || !X || X->kind != GLF_MAT_DENSE) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     return normalise(ctx, X->data, (unsigned)X->rows, (unsigned)X->cols, (unsigned)X->ld, norms);
 }
 
 int glf_InverseDiagMat(glf_ctx *ctx, const glf_mat *x, glf_mat *inv)
 {
     if (!ctx || !x || !inv || x->kind != GLF_MAT_DIAG) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     GLF_TRY(glf_mat_create_diag(ctx, inv, x->rows));
     const unsigned n = (unsigned)x->rows;
     hipLaunchKernelGGL(k_diag_inverse, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, x->data, n, inv->data);
@@ -245,6 +251,7 @@ int glf_InverseDiagMat(glf_ctx *ctx, const glf_mat *x, glf_mat *inv)
 int glf_Nystroem(glf_ctx *ctx, const glf_mat *B, const glf_mat *phi_A, const glf_mat *Pi_A_Inv, glf_mat *phi)
 {
     if (!ctx || !B || !phi_A || !Pi_A_Inv || !phi) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     if (B->kind != GLF_MAT_KERNEL_B || phi_A->kind != GLF_MAT_DENSE || Pi_A_Inv->kind != GLF_MAT_DIAG)
         return set_error(ctx, GLF_ERR_INVALID, "Nystroem: B must be a KERNEL_B descriptor, phi_A dense, Pi_A_Inv diagonal");
     const unsigned p = B->p, m = (unsigned)phi_A->cols, ld = (unsigned)phi_A->ld;
@@ -271,6 +278,7 @@ int glf_Nystroem(glf_ctx *ctx, const glf_mat *B, const glf_mat *phi_A, const glf
 int glf_Permutation(glf_ctx *ctx, const glf_mat *in, const unsigned *sample_indices, unsigned num, glf_mat *out)
 {
     if (!ctx || !in || !out || in->kind != GLF_MAT_DENSE || !sample_indices) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     DevBuf<uint32_t> idx;
     GLF_TRY(idx.alloc(ctx, num));
     GLF_TRY(glf_memcpy_h2d(ctx, idx.p, sample_indices, sizeof(uint32_t) * num));
@@ -285,6 +293,7 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
                                    unsigned height, float gain, uint8_t *d_out, float *d_zf)
 {
     if (!ctx || !d_img || !phi || !Pi || !d_out) return GLF_ERR_INVALID;
+    GLF_ENTER(ctx);
     const int64_t N = (int64_t)width * height;
     const unsigned m = (unsigned)phi->cols, ld = (unsigned)phi->ld;
     if (phi->kind != GLF_MAT_DENSE || phi->rows != N || Pi->kind != GLF_MAT_DIAG || Pi->rows != m || !valid_ld(ld))
@@ -312,6 +321,7 @@ int glf_EntireComputation(glf_ctx *ctx, const uint8_t *d_img, int width, int hei
 {
     if (!ctx || !d_img || !d_out || width <= 0 || height <= 0) return GLF_ERR_INVALID;
     if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
+    GLF_ENTER(ctx);
     return entire_computation(ctx, d_img, width, height, make_coef(kernel, h_loc, h_val), d_out, d_zf, alpha_out);
 }
 
@@ -322,7 +332,16 @@ int glf_EntireComputation(glf_ctx *ctx, const uint8_t *d_img, int width, int hei
 int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t *d_img, int width, int height,
                          uint8_t *d_out, float *d_zf, double *eigvals_out, glf_stats *stats)
 {
+    return glf_image_processing_capture(ctx, opt_in, d_img, width, height, d_out, d_zf, eigvals_out, stats, nullptr);
+}
+
+int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const uint8_t *d_img, int width, int height,
+                                 uint8_t *d_out, float *d_zf, double *eigvals_out, glf_stats *stats, glf_capture *cap)
+{
     if (!ctx || !d_img || !d_out || width <= 0 || height <= 0) return GLF_ERR_INVALID;
+    if (cap && cap->struct_size != sizeof(glf_capture))
+        return set_error(ctx, GLF_ERR_INVALID, "glf_capture.struct_size %u != %zu", cap->struct_size, sizeof(glf_capture));
+    GLF_ENTER(ctx);
     glf_options opt;
     glf_options_default(&opt);
     if (opt_in) {
@@ -375,6 +394,15 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
                              &S.degree_evaluated));
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    if (cap) {
+        cap->ld = ld;
+        if (cap->h_degree) {
+            GLF_HIP(ctx, hipMemcpyAsync(cap->h_degree, deg.p, sizeof(double) * p, hipMemcpyDeviceToHost, st));
+            GLF_HIP(ctx, hipStreamSynchronize(st));
+        }
+        if ((cap->d_phi_A && cap->phi_A_floats < (size_t)p32 * ld) || (cap->d_phi && cap->phi_floats < (size_t)(pix1 - pix0) * ld))
+            return set_error(ctx, GLF_ERR_INVALID, "glf_capture: phi_A needs %zu floats, phi %zu", (size_t)p32 * ld, (size_t)(pix1 - pix0) * ld);
+    }
     // ---- Laplacian ---------------------------------------------------------------------------
     double dsum = 0.0;
     GLF_TRY(sum_host(ctx, deg.p, p, &dsum));
@@ -446,6 +474,7 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
         if (rc != GLF_OK) return rc;
     }
     LA.release();
+    if (cap && cap->d_phi_A) GLF_HIP(ctx, hipMemcpyAsync(cap->d_phi_A, phiA.p, sizeof(float) * (size_t)p32 * ld, hipMemcpyDeviceToDevice, st));
     if (eigvals_out)
         for (unsigned j = 0; j < m; ++j) eigvals_out[j] = lam[j];
     GLF_HIP(ctx, hipEventRecord(ctx->ev[3], st));
@@ -499,7 +528,9 @@ int glf_image_processing(glf_ctx *ctx, const glf_options *opt_in, const uint8_t 
     {
         std::vector<double> hc(ld);
         GLF_HIP(ctx, hipMemcpyAsync(hc.data(), c.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
+        if (cap && cap->d_phi) GLF_HIP(ctx, hipMemcpyAsync(cap->d_phi, phi.p, sizeof(float) * (size_t)npix * ld, hipMemcpyDeviceToDevice, st));
         GLF_HIP(ctx, hipStreamSynchronize(st));
+        if (cap && cap->h_c) std::memcpy(cap->h_c, hc.data(), sizeof(double) * ld);
         std::vector<float> hw(ld, 0.f);
         // f(Pi): MatPow(eigvals, 6) is a no-op in the reference (hpc/utils.c:721) => filter_pow = 1
         for (unsigned j = 0; j < m; ++j) hw[j] = (float)(std::pow(lam[j], (double)(opt.filter_pow > 0 ? opt.filter_pow : 1)) * hc[j]);

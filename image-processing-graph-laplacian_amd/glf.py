@@ -43,7 +43,7 @@ EXPORTS = [
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
     "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
-    "glf_options_default", "glf_image_processing", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png",
+    "glf_options_default", "glf_image_processing", "glf_image_processing_capture", "glf_ctx_debug_violations", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png",
 ]
 
 
@@ -84,6 +84,11 @@ class Stats(C.Structure):
         ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("matvec_path", C.c_int32),
         ("nystroem_rowpass_launches", C.c_int32), ("nystroem_rowpass_ms", C.c_float), ("nystroem_rowpass_flops", C.c_double),
     ]
+
+
+class Capture(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("ld", C.c_uint32), ("d_phi_A", C.c_void_p), ("phi_A_floats", C.c_size_t),
+                ("d_phi", C.c_void_p), ("phi_floats", C.c_size_t), ("h_c", C.c_void_p), ("h_degree", C.c_void_p)]
 
 
 ALLREDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -253,6 +258,10 @@ class Context:
 
     def synchronize(self):
         self._check(_lib.glf_ctx_synchronize(self._ctx))
+
+    def debug_violations(self):
+        """Guard zones of work buffers found overwritten (debug pool, GLF_POOL_DEBUG=1 at creation); -1 otherwise."""
+        return int(_lib.glf_ctx_debug_violations(self._ctx))
 
     def device_info(self):
         name = C.create_string_buffer(256)
@@ -450,8 +459,10 @@ class Context:
         self.stream.synchronize()
         return out, zf, alpha.value
 
-    def image_processing(self, d_img, opt=None, want_float=False, out=None):
-        """Whole approximate path (hpc/image_processing.c:183-277) on a device image tensor."""
+    def image_processing(self, d_img, opt=None, want_float=False, out=None, capture=False):
+        """Whole approximate path (hpc/image_processing.c:183-277) on a device image tensor.
+        capture=True additionally returns the run's by-products in info["capture"] (glf_capture): phi_A [p, ld] and
+        phi [rows of this rank * width, ld] as device tensors, c = Phi^T y and the degree vector as numpy arrays."""
         torch = self.torch
         assert d_img.dtype == torch.uint8 and d_img.is_cuda and d_img.dim() == 2 and d_img.is_contiguous()
         h, w = d_img.shape
@@ -461,10 +472,27 @@ class Context:
                 out = torch.zeros((h, w), dtype=torch.uint8, device=self.device)
             zf = torch.zeros((h, w), dtype=torch.float32, device=self.device) if want_float else None
         st = Stats()
-        lam = np.zeros(256, dtype=np.float64)
-        rc = _lib.glf_image_processing(self._ctx, C.byref(opt), C.c_void_p(d_img.data_ptr()), C.c_int(w), C.c_int(h),
-                                       C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None,
-                                       lam.ctypes.data_as(C.c_void_p), C.byref(st))
+        lam = np.zeros(4096, dtype=np.float64)
+        cap, keep = None, None
+        if capture:
+            # the realised sample count (hpc/sampling.c rewrites the request) and the row stride, known before the call
+            p_max = int(Sampling(w, h, int(opt.num_samples) if opt.num_samples else int(h * w * opt.sample_frac)).size)
+            m_req = int(opt.num_eigvals) if 0 < opt.num_eigvals < p_max else max(1, p_max - 1)
+            ld = 32
+            while ld < min(m_req, 256):
+                ld *= 2
+            rows = shard_rows(h, self._comm_keepalive.rank, self._comm_keepalive.size) if self._comm_keepalive else (0, h)
+            npix = (rows[1] - rows[0]) * w
+            with torch.cuda.stream(self.stream):
+                phi_A = torch.zeros(((p_max + 63) // 64 * 64, ld), dtype=torch.float32, device=self.device)
+                phi = torch.zeros((npix, ld), dtype=torch.float32, device=self.device)
+            c_host, deg_host = np.zeros(ld, dtype=np.float64), np.zeros(p_max, dtype=np.float64)
+            cap = Capture(C.sizeof(Capture), 0, phi_A.data_ptr(), phi_A.numel(), phi.data_ptr(), phi.numel(),
+                          c_host.ctypes.data, deg_host.ctypes.data)
+            keep = (phi_A, phi, c_host, deg_host)
+        rc = _lib.glf_image_processing_capture(self._ctx, C.byref(opt), C.c_void_p(d_img.data_ptr()), C.c_int(w), C.c_int(h),
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None,
+                                               lam.ctypes.data_as(C.c_void_p), C.byref(st), C.byref(cap) if cap else None)
         self._check(rc, "image_processing")
         self.stream.synchronize()
         info = dict(p=st.p, m=st.m, alpha=st.alpha, outer_its=st.eig.outer_its,
@@ -479,6 +507,10 @@ class Context:
                     nystroem_rowpass_flops=st.nystroem_rowpass_flops,
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     eigvals=lam[:st.m].copy())
+        if capture:
+            assert cap.ld == keep[0].shape[1], (cap.ld, keep[0].shape)
+            info["capture"] = dict(phi_A=keep[0][:st.p], phi=keep[1], c=keep[2][:st.m].copy(), degree=keep[3][:st.p].copy(),
+                                   ld=int(cap.ld))
         return out, zf, info
 
 

@@ -62,6 +62,12 @@ const char *glf_ctx_last_error(const glf_ctx *ctx);
 /* Device name / CU count / memory, for reports. */
 int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *num_cus,
                         size_t *total_mem_bytes);
+/* Debug workspace pool (environment GLF_POOL_DEBUG=1 at context creation; no reference counterpart): every work
+ * buffer is allocated at its exact size followed by a 4 KiB guard zone of canary bytes, floating-point buffers are
+ * handed out filled with NaN instead of whatever an earlier call left in them, nothing is reused, and the guard is
+ * verified when the buffer is released. Returns the number of guard zones found overwritten so far (0 = no kernel
+ * wrote past the end of a work buffer), -1 when the context was not created in debug mode. */
+int glf_ctx_debug_violations(const glf_ctx *ctx);
 
 /* Collectives supplied by the caller (replace the MPI_Allreduce / allgather
  * inside PETSc's VecDot, VecSum, MatMult: hpc/gram_schmidt.c:14-15,
@@ -274,6 +280,22 @@ typedef struct glf_stats {
 int glf_image_processing(glf_ctx *ctx, const glf_options *opt, const uint8_t *d_img, int width,
                          int height, uint8_t *d_out, float *d_zf, double *eigvals_out,
                          glf_stats *stats);
+
+/* By-products of one glf_image_processing call, for parity checks at sizes where the CPU oracle cannot run the whole
+ * path (tests/test_gpu_large.py, bench.py's parity leg): the caller checks sampled rows of Phi / z against
+ * hpc/nystroem.c:41-57 and hpc/display.c:58-83 evaluated on the CPU from these. Every pointer is optional. */
+typedef struct glf_capture {
+    uint32_t struct_size;  /* sizeof(glf_capture) */
+    uint32_t ld;           /* out: row stride of phi_A / phi (m rounded up to 32, 64, 128 or 256) */
+    float *d_phi_A;        /* device [p rounded up to 64][ld]: the eigenvectors (hpc/inverse_power_it.c:213-241) */
+    size_t phi_A_floats;   /* capacity of d_phi_A in floats (GLF_ERR_INVALID when too small) */
+    float *d_phi;          /* device [pixels of this rank][ld]: Phi in raster order after Nystroem + Permutation */
+    size_t phi_floats;     /* capacity of d_phi in floats */
+    double *h_c;           /* host [ld]: right = Phi^T y (hpc/display.c:66), summed over all ranks */
+    double *h_degree;      /* host [p]: D_A = rowsum [K_A K_B] (hpc/laplacian.c:18-20), summed over all ranks */
+} glf_capture;
+int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt, const uint8_t *d_img, int width, int height,
+                                 uint8_t *d_out, float *d_zf, double *eigvals_out, glf_stats *stats, glf_capture *cap);
 
 /* Throughput mode for a batch of equally sized tiles (BASELINE.json configs[4]: "batch of 64 x 1024x1024 noisy tiles
  * sharing one sample set"; hpc/sampling.c:6-23 gives tiles of one size the same sample grid). The reference would run its

@@ -1,0 +1,233 @@
+"""The benchmark-sized configurations under test (-m gpu): BASELINE cfg3 (2048^2, 0.5 %, m = 64) and cfg4 (4096^2, the
+headline), through the kernels bench.py times (grid-factored degree, L_A operator, Nystroem passes incl. the
+2048-row pass boundary), against the fp64 oracle on sampled slices -- the oracle cannot run those sizes whole
+(4096^2: ~2 h on 128 threads).
+
+  degree      D_A on ~48 samples spread over the grid vs orc.degree (hpc/laplacian.c:18-20)          rel 2e-6
+  eigenpairs  2048^2: the oracle's whole eigen-solve (hpc/inverse_power_it.c:86-252) on L_A built from the oracle's
+              K_A and the GPU's degree vector, same X0 / stopping rule, iteration count pinned when it differs;
+              both sizes: the reported residual || (I - X X^T) A X ||_F recomputed in fp64 from a dense L_A
+  Phi rows    orc.nystroem_rows (hpc/nystroem.c:41-57) fed the GPU's Phi_A, eigenvalues, alpha: rows 0, 1, the pass
+              boundary H/2 - 1 | H/2, H - 33, H - 1, ...                                   abs 2e-5 * max|Phi|
+  z rows      hpc/display.c:58-83 on those rows with c = Phi^T y recomputed in fp64: error measured on the
+              correction z - y (rel-L2 <= 2e-4), u8: >= 99.9 % within one grey level, PSNR >= 50 dB
+
+Arithmetic (SURVEY 8d "fp32"): every contraction of the default path multiplies operands split into f16 (hi, lo) pairs
+(22 significant bits, f32 accumulation). test_contraction_arithmetic_bounds compares that against the exact-f32-operand
+MFMA kernels and the fp64 oracle on Phi and on z - y, incl. kernels with a large dynamic range.
+"""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import glf  # noqa: E402
+import oracle as orc  # noqa: E402
+import parity  # noqa: E402  (oracle/parity.py)
+from conftest import ROOT  # noqa: E402
+from test_abi import SYNTH_CRC32  # noqa: E402
+
+PHI_TOL = 2e-5          # max |Phi_gpu - Phi_ref| / max |Phi_ref| over the checked rows
+CORR_TOL = 2e-4         # || z_gpu - z_ref || / || z_ref - y || over the checked rows
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    c = glf.Context(0)
+    yield c
+    c.close()
+
+
+def _record(name, payload):
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(payload, f, indent=1, default=float)
+
+
+def _dense_LA_tensor(ctx, d_img, idx):
+    """L_A through the stage API (k_sample_matrix: entries checked against the oracle by test_gpu_parity.py and below)."""
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    L_A, _, alpha = ctx.ComputeLaplacianMatrix(None, K_B)
+    t = glf.device_tensor_from_ptr(L_A.data, int(L_A.rows) * int(L_A.ld), ctx.torch.float32, ctx.device).view(int(L_A.rows), int(L_A.ld))
+    return t, L_A, K_B, alpha
+
+
+def _residual_fp64(torch, LA, p, X):
+    """|| A Q - Q (Q^T A Q) ||_F in fp64 for Q = orth(X) (the norm depends on span(X) only); also the Ritz values."""
+    Q, _ = torch.linalg.qr(X.double())
+    AQ = torch.empty_like(Q)
+    for i0 in range(0, p, 4096):
+        i1 = min(p, i0 + 4096)
+        AQ[i0:i1] = LA[i0:i1, :p].double() @ Q
+    G = Q.T @ AQ
+    R = AQ - Q @ G
+    return float(torch.linalg.norm(R)), torch.linalg.eigvalsh(0.5 * (G + G.T)).cpu().numpy()
+
+
+@pytest.mark.parametrize("size", [2048, 4096])
+def test_headline_config_sampled_parity(ctx, size):
+    torch = ctx.torch
+    img = glf.synth_image(size, size, seed=0)
+    assert zlib.crc32(img.tobytes()) == SYNTH_CRC32[size]
+    N, m, eps = size * size, 64, 0.1
+    ns = int(N * 0.005)
+    idx = glf.Sampling(size, size, ns)
+    p = idx.size
+    assert p == {2048: 21316, 4096: 85264}[size]
+    d_img = ctx.to_device(img)
+    opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    out, zf, info = ctx.image_processing(d_img, opt, want_float=True, capture=True)
+    cap = info["capture"]
+    # the kernel families bench.py times
+    assert info["nystroem_path"] == 1 and info["matvec_path"] == 1 and info["contraction"] == glf.CONTRACT_F16_SPLIT
+    assert (info["p"], info["m"], cap["ld"]) == (p, m, 64)
+    assert torch.isfinite(zf).all() and info["residual"] <= eps
+    report = {"size": size, "p": p, "m": m, "outer_its": info["outer_its"], "inner_its_total": info["inner_its_total"],
+              "residual": info["residual"], "ms_total": info["ms_total"]}
+
+    # ---- degree on a sub-sample of the samples, alpha -----------------------------------------------------------------
+    D = cap["degree"]
+    sub = np.unique(np.concatenate([np.arange(0, p, max(1, p // 40)), [p - 1, p // 2]])).astype(np.int64)
+    D_ref = orc.degree(img, idx[sub])
+    np.testing.assert_allclose(D[sub], D_ref, rtol=2e-6)
+    assert info["alpha"] == pytest.approx(p / D.sum(), rel=1e-12)
+    report["degree_max_rel"] = float(np.max(np.abs(D[sub] / D_ref - 1.0)))
+
+    # ---- eigenpairs ------------------------------------------------------------------------------------------------------
+    LA_t, L_A, K_B, alpha_stage = _dense_LA_tensor(ctx, d_img, idx)
+    assert alpha_stage == pytest.approx(info["alpha"], rel=1e-12)
+    # rows of the dense L_A against the oracle (first, middle, last sample)
+    for i in (0, p // 2, p - 1):
+        row_ref = orc.laplacian_rows(img, idx, D, info["alpha"], i, i + 1)[0]
+        np.testing.assert_allclose(LA_t[i, :p].cpu().numpy(), row_ref, rtol=0, atol=3e-6 * np.abs(row_ref).max())
+    phi_A = cap["phi_A"][:, :m]
+    np.testing.assert_allclose(torch.linalg.norm(phi_A.double(), dim=0).cpu().numpy(), 1.0, rtol=2e-6)   # NormaliseVecs, :230
+    res64, ritz = _residual_fp64(torch, LA_t, p, phi_A)
+    report["residual_fp64_from_dense_LA"] = res64
+    assert res64 == pytest.approx(info["residual"], rel=2e-2)      # the stopping rule's quantity, recomputed independently
+    lam = info["eigvals"]
+    assert np.all(np.isfinite(lam)) and np.all(lam > 0)
+    report["eigval_vs_ritz_max_rel"] = float(np.max(np.abs(np.sort(lam) / ritz - 1.0)))
+    assert report["eigval_vs_ritz_max_rel"] <= 0.1                    # sanity only: 1 / |u_j| estimates (:204) at eps = 0.1
+    if size == 2048:
+        KA, _ = orc.affinity(img, idx, want_KB=False)
+        LA_ref, alpha_ref = orc.laplacian(KA, D)
+        del KA
+        assert alpha_ref == pytest.approx(info["alpha"], rel=1e-12)
+        X0 = glf.random_vectors(p, m, 1)
+        vecs_ref, vals_ref, st_ref, free_its = parity.oracle_ipi_matching(LA_ref, m, X0, eps, info["outer_its"], inner_rtol=1e-5)
+        assert abs(free_its - info["outer_its"]) <= 1
+        del LA_ref
+        np.testing.assert_allclose(lam, vals_ref, atol=2e-4)
+        V = phi_A.cpu().numpy().T.astype(np.float64)
+        report["eigvec_max_abs_err"] = float(np.abs(V - vecs_ref).max())
+        np.testing.assert_allclose(V, vecs_ref, atol=2e-3)
+        report["oracle_outer_its_free"] = free_its
+    del LA_t
+    ctx.destroy(L_A, K_B)
+
+    # ---- Phi rows and z rows ---------------------------------------------------------------------------------------------
+    phi = cap["phi"]                                                   # [N, 64] raster order
+    y64 = d_img.reshape(-1).double()
+    c64 = (phi.double().T @ y64).cpu().numpy()[:m]
+    np.testing.assert_allclose(cap["c"], c64, rtol=0, atol=1e-6 * np.abs(c64).max())    # the library's Phi^T y reduction
+    report["c_max_rel"] = float(np.abs(cap["c"] - c64).max() / np.abs(c64).max())
+    half = size // 2                                                   # 4096: the boundary between the two 2048-row passes
+    rows = sorted({0, 1, 33, half - 1, half, half + 1, size - 33, size - 1, 1000})
+    phi_v = phi.view(size, size, 64)
+    res = parity.check_rows(img, idx, info["alpha"], phi_A.cpu().numpy(), lam, c64, rows,
+                            phi_gpu=lambda r: phi_v[r, :, :m].cpu().numpy(), zf_gpu=lambda r: zf[r].cpu().numpy(),
+                            out_gpu=lambda r: out[r].cpu().numpy(), gain=3.0)
+    report["rows_check"] = res
+    _record("large_parity_%d.json" % size, report)
+    print(json.dumps(report, default=float))
+    assert res["phi_max_abs_err_over_max"] <= PHI_TOL
+    assert res["rel_l2_correction"] <= CORR_TOL
+    assert res["u8_within1_frac"] >= 0.999 and res["u8_max_diff"] <= 1
+    assert res["psnr_db"] >= 50.0
+    # the whole image: every pixel's correction follows from its Phi row -- z recomputed in fp64 from the captured Phi
+    wv = torch.from_numpy(3.0 * lam * c64).to(ctx.device)
+    z_all = y64 + phi[:, :m].double() @ wv
+    corr = z_all - y64
+    rel_all = float(torch.linalg.norm(zf.reshape(-1).double() - z_all) / torch.linalg.norm(corr))
+    report_all = rel_all
+    assert rel_all <= 1e-4, rel_all                                   # the filter kernel itself (f32 dot of 64 terms, z stored as f32)
+    out_all = torch.clamp(z_all, 0.0, 255.0).to(torch.uint8)
+    assert float((out_all.reshape(size, size) != out).double().mean()) <= 1e-4   # f32 vs f64 rounding at integer boundaries
+
+
+HDR_KERNELS = [
+    # (h_loc, h_val): the reference's constants; a narrow spatial kernel (the radius where 2^15 Er rounds to a zero f16,
+    # 5.3 h_loc, falls inside the sample neighbourhood the f32 kernels still see out to 10.2 h_loc) with a flat
+    # photometric factor; and a sharp photometric factor (entries down to the f32 denormals)
+    (40.0, 30.0), (6.0, 400.0), (40.0, 5.0),
+]
+
+
+@pytest.mark.parametrize("size", [1024, 2048])
+def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
+    """Phi and z - y from (a) the default grid-factored split-f16 contraction, (b) the entry-by-entry split-f16 kernel and
+    (c) the exact-f32-operand MFMA kernel, each against the fp64 oracle on sampled rows; same Phi_A / eigenvalues for all
+    three (one eigen-solve)."""
+    torch = ctx.torch
+    img = glf.synth_image(size, size, seed=0)
+    assert zlib.crc32(img.tobytes()) == SYNTH_CRC32[size]
+    N, m = size * size, 64
+    ns = int(N * 0.005)
+    idx = glf.Sampling(size, size, ns)
+    p = idx.size
+    d_img = ctx.to_device(img)
+    y64 = d_img.reshape(-1).double()
+    rows = [0, size // 2 - 1, size // 2, size - 1]
+    report = {}
+    for h_loc, h_val in (HDR_KERNELS if size == 1024 else HDR_KERNELS[:1]):
+        prm = orc.default_params()
+        prm.h_loc, prm.h_val = h_loc, h_val
+        ctx.set_contraction(glf.CONTRACT_F16_SPLIT)
+        _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False, h_loc=h_loc, h_val=h_val)
+        L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(None, K_B)
+        # eigenpairs of this L_A (LAPACK on the host at 1024^2 would take minutes: the library's own solve, once)
+        vecs, vals, st = ctx.InversePowerIteration(L_A, m, epsilon=0.1, allow_noconv=True, max_outer=8)
+        lam = ctx.mat_to_numpy(vals).astype(np.float64)
+        phi_A = ctx.mat_to_numpy(vecs)
+        Pi_inv = ctx.InverseDiagMat(vals)
+        got = {}
+        for mode in ("grid_f16s", "direct_f16s", "direct_f32"):
+            ctx.set_contraction(glf.CONTRACT_F32_MFMA if mode == "direct_f32" else glf.CONTRACT_F16_SPLIT)
+            monkeypatch.setenv("GLF_NYS_PATH", "grid" if mode == "grid_f16s" else "direct")
+            phi_sf = ctx.Nystroem(L_B, vecs, Pi_inv)
+            phi = ctx.Permutation(phi_sf, idx)
+            ctx.destroy(phi_sf)
+            out, zf = ctx.ComputeResultFromLaplacian(d_img, phi, vals, gain=3.0)
+            pt = glf.device_tensor_from_ptr(phi.data, N * int(phi.ld), torch.float32, ctx.device).view(size, size, int(phi.ld))
+            c64 = (pt.reshape(N, -1).double().T @ y64).cpu().numpy()[:m]
+            res = parity.check_rows(img, idx, alpha, phi_A, lam, c64, rows, phi_gpu=lambda r: pt[r, :, :m].cpu().numpy(),
+                                    zf_gpu=lambda r: zf[r].cpu().numpy(), out_gpu=lambda r: out[r].cpu().numpy(), gain=3.0, prm=prm)
+            got[mode] = (pt[rows].clone(), res)
+            del pt
+            ctx.destroy(phi)
+        monkeypatch.delenv("GLF_NYS_PATH", raising=False)
+        ctx.set_contraction(glf.CONTRACT_F16_SPLIT)
+        key = "%dx%d h_loc=%g h_val=%g" % (size, size, h_loc, h_val)
+        report[key] = {mode: got[mode][1] for mode in got}
+        for mode, (_, res) in got.items():
+            assert res["phi_max_abs_err_over_max"] <= PHI_TOL, (key, mode, res)
+            assert res["rel_l2_correction"] <= CORR_TOL, (key, mode, res)
+            assert res["u8_within1_frac"] >= 0.999, (key, mode, res)
+        # the split-f16 results against the exact-f32-operand kernel directly (same rows): the 22-bit operands cost less
+        # than the fp32 accumulation already does
+        ref32 = got["direct_f32"][0].double()
+        for mode in ("grid_f16s", "direct_f16s"):
+            d = float((got[mode][0].double() - ref32).abs().max() / ref32.abs().max())
+            report[key][mode + "_vs_f32_max_abs_over_max"] = d
+            assert d <= PHI_TOL, (key, mode, d)
+        ctx.destroy(L_A, vecs, vals, Pi_inv, K_B)
+    _record("arithmetic_%d.json" % size, report)
+    print(json.dumps(report, default=float))
