@@ -10,7 +10,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result
 CFLAGS   ?= -O2 -std=gnu11 -Wall -Wextra -fPIC
 
 HIP_SRCS := $(CSRC)/ctx.hip $(CSRC)/affinity.hip $(CSRC)/eigen.hip $(CSRC)/nystroem.hip \
-            $(CSRC)/filter.hip $(CSRC)/pipeline.hip
+            $(CSRC)/filter.hip $(CSRC)/pipeline.hip $(CSRC)/comm.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 CPP_OBJS := $(CSRC)/host_util.o
 C_OBJS   := $(HOST)/png_codec.o
@@ -27,7 +27,7 @@ $(HOST)/%.o: $(HOST)/%.c include/glf.h $(HOST)/stages.h
 	gcc $(CFLAGS) -Iinclude -c $< -o $@
 
 $(PKG)/libglf.so: $(HIP_OBJS) $(CPP_OBJS) $(C_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz -pthread -ldl
 
 $(PKG)/image_processing: $(HOST)/image_processing.o $(HOST)/stages.o $(PKG)/libglf.so
 	gcc -o $@ $(HOST)/image_processing.o $(HOST)/stages.o -L$(PKG) -lglf -Wl,-rpath,'$$ORIGIN' -lm

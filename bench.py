@@ -31,6 +31,8 @@ import glf  # noqa: E402  (HIP path; raises if libglf.so is missing)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)" dense
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0
+# glf_synth_image(size, size, seed 0): the workload is pinned byte for byte (same table as tests/test_abi.py)
+SYNTH_CRC32 = {1024: 0x3d97f4f9, 2048: 0x40fa122b, 4096: 0xdc7203de}
 
 
 def parse_args():
@@ -52,7 +54,12 @@ def parse_args():
     ap.add_argument("--batch-tile-size", type=int, default=1024)
     ap.add_argument("--batch-contexts", type=int, default=8)
     ap.add_argument("--force-comm", action="store_true",
-                    help="diagnostic: one rank, but with the RCCL callbacks plugged in (cost of the N > 1 plumbing)")
+                    help="diagnostic: one rank, but with the RCCL collectives in place (cost of the N > 1 plumbing)")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1 collectives: rccl = issued by the library itself on its stream (glf_ctx_set_comm_rccl, "
+                         "default); torch = torch.distributed callbacks through ctypes (the round-1 path, kept for comparison)")
+    ap.add_argument("--no-direct-leg", action="store_true",
+                    help="skip the direct_contraction leg (one step with the entry-by-entry Nystroem kernel, ~0.5 s)")
     return ap.parse_args()
 
 
@@ -73,8 +80,8 @@ def cpu_baseline(img, info, args):
     t0 = time.time()
     orc.degree(img, idx, row0=h // 2, row1=h // 2 + rows_deg)
     t_deg = (time.time() - t0) * h / rows_deg
-    # L_A rows band + block mat-vec on it
-    D = np.full(p, 1800.0)
+    # L_A rows band + block mat-vec on it (D_A of the GPU run: the diagonal of L_A)
+    D = np.ascontiguousarray(info["capture"]["degree"]) if "capture" in info else np.full(p, 1800.0)
     band = max(32, min(p, int(2e9 / p)))                          # ~2e9 entries
     t0 = time.time()
     Arows = orc.laplacian_rows(img, idx, D, info["alpha"], 0, band)
@@ -135,6 +142,35 @@ def cpu_parity_cfg2(ctx):
     }
 
 
+def parity_headline(ctx, img, cap_run, args):
+    """Sampled-row check of the benchmark-size run itself (the oracle's whole path would take ~2 h at 4096^2): the
+    oracle's Nystroem rows (hpc/nystroem.c:41-57) from the run's own Phi_A / eigenvalues / alpha and the filter
+    (hpc/display.c:58-83) on rows 0, the pass boundary H/2 - 1 | H/2, and H - 1, against the run's Phi, correction and u8
+    output; plus D_A on a few samples. tests/test_gpu_large.py asserts the same quantities on more rows."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    import parity
+    out, zf, info = cap_run
+    cap = info["capture"]
+    size = img.shape[0]
+    m = info["m"]
+    idx = glf.Sampling(size, size, int(size * size * args.sample_frac))
+    t0 = time.time()
+    sub = np.unique(np.linspace(0, idx.size - 1, 12).astype(np.int64))
+    d_rel = float(np.max(np.abs(cap["degree"][sub] / orc.degree(img, idx[sub]) - 1.0)))
+    rows = sorted({0, size // 2 - 1, size // 2, size - 1})
+    phi_v = cap["phi"].view(size, size, cap["ld"])
+    corr_v = cap["corr"].view(size, size)
+    res = parity.check_rows(img, idx, info["alpha"], cap["phi_A"][:, :m].cpu().numpy(), info["eigvals"], cap["c"], rows,
+                            phi_gpu=lambda r: phi_v[r, :, :m].cpu().numpy(), zf_gpu=lambda r: zf[r].cpu().numpy(),
+                            out_gpu=lambda r: out[r].cpu().numpy(), gain=3.0, corr_gpu=lambda r: corr_v[r].cpu().numpy())
+    res["degree_max_rel_err_12_samples"] = d_rel
+    res["cpu_seconds"] = round(time.time() - t0, 1)
+    res["what"] = ("rows %s of the %dx%d run vs the fp64 oracle fed the run's Phi_A, eigenvalues, alpha and c = Phi^T y; "
+                   "psnr_db / u8_* on the 8-bit output rows, rel_l2_correction on z - y" % (rows, size, size))
+    return res
+
+
 def run_batch_leg(args, ctx, rank, world, barrier):
     """BASELINE config 5: a batch of equally sized tiles (one sample grid), replicas only. The tiles are split evenly over
     the ranks; each rank deals its share to `--batch-contexts` contexts working concurrently (glf_image_processing_batch)
@@ -191,9 +227,18 @@ def main():
     size = args.size
     N = size * size
     img = glf.synth_image(size, size, seed=0)      # byte-identical on every rank
+    import zlib
+    crc = zlib.crc32(img.tobytes())
+    if size in SYNTH_CRC32 and crc != SYNTH_CRC32[size]:
+        raise SystemExit("synthetic %dx%d image has CRC32 %08x, expected %08x (tests/test_abi.py)" % (size, size, crc, SYNTH_CRC32[size]))
     ctx = glf.Context(local_rank)
     if world > 1 or args.force_comm:
-        ctx.set_comm_torch(force=args.force_comm)
+        if args.comm == "rccl":   # the library issues its own RCCL collectives: the id travels through torch.distributed once
+            box = [glf.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.set_comm_rccl(rank, world, box[0], force=args.force_comm)
+        else:
+            ctx.set_comm_torch(force=args.force_comm)
     d_img = ctx.to_device(img)
     d_out = torch.zeros((size, size), dtype=torch.uint8, device=ctx.device)
     opt = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals, epsilon=args.epsilon)
@@ -246,6 +291,26 @@ def main():
                                        epsilon=args.epsilon, skip_exact_zeros=1)
         skip_leg = run_leg(opt_skip)
 
+    # direct_contraction leg: ONE step with the entry-by-entry Nystroem kernel (k_nystroem_f16s: K_B generated in registers,
+    # the "true dense contraction" of north_star, SURVEY 8d's W_nys = 2 (N - p) p m) so that it has a driver-timed number
+    direct_leg = None
+    if not args.no_direct_leg and info["nystroem_path"] == 1:
+        os.environ["GLF_NYS_PATH"] = "direct"
+        try:
+            ctx.image_processing(d_img, opt, out=d_out)          # warm-up (tables, pool)
+            barrier()
+            _, _, dinfo = ctx.image_processing(d_img, opt, out=d_out)
+            barrier()
+            direct_leg = dinfo
+        finally:
+            del os.environ["GLF_NYS_PATH"]
+
+    # parity leg input: one more (untimed) run of the headline configuration with its by-products captured
+    cap_run = None
+    if world == 1 and not args.no_parity and not args.no_cpu_baseline:
+        cap_run = ctx.image_processing(d_img, opt, want_float=True, capture=True)
+        info["capture"] = cap_run[2]["capture"]
+
     batch_leg = None
     if not args.no_batch_leg:
         batch_leg = run_batch_leg(args, ctx, rank, world, barrier)
@@ -294,12 +359,15 @@ def main():
         prof = {}
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this configuration
             key = "%dx%d_m%d_%s_gpus%d" % (size, size, m, "f16s" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32", n_gpus)
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(key, {})
+            prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key, {})
         except (OSError, ValueError):
             pass
         sweeps = {"path": "grid-factored (L_A never stored)" if info["matvec_path"] == 1 else "stored L_A streamed (k_block_matvec_f16s)",
                   "launches_per_step": mvs["launches"] / args.steps, "avg_ms": round(mv_avg_ms, 4),
                   "ms_per_step": round(mvs["ms"] / args.steps, 3)}
+        # (image row, value) pairs that occur in the image: the T rows the row pass has to deliver (the others are computed
+        # by the 32-row MFMA tiles but never stored or read)
+        present = float(np.mean([np.unique(img[r]).size for r in range(info["row0"], info["row1"])])) / 256.0
         if info["matvec_path"] == 1 and rps["launches"] > 0:
             # dominant kernel: the row pass of the Nystroem contraction (k_grid_rowpass_rt; by name the largest share of the step)
             rp_avg_ms = rps["ms"] / rps["launches"]
@@ -313,13 +381,17 @@ def main():
                           "the same sums over the grid rows with k_grid_rowpass)" % (min(ld, 64) // 32),
                 "bound": "mfma", "achieved": round(rp_tflops, 1), "peak": round(rp_peak, 1), "unit": "TFLOP/s",
                 "frac": round(rp_tflops / rp_peak, 4), "traffic": prof.get("grid_rowpass_bytes_per_launch"),
+                "traffic_source": prof.get("grid_rowpass_source", "none: no committed --pmc pass for this configuration"),
+                "useful_work_frac": round(present, 4), "frac_useful": round(rp_tflops / rp_peak * present, 4),
                 "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add (nominal; "
                               "tools/mfma16_probe.hip: v_mfma_f32_32x32x16_f16 sustains 1750 TFLOP/s from registers and 1670 with "
                               "B fragments from LDS on pseudo-random operands, 2450 on all-zero operands -- power-limited)",
                 "avg_launch_ms": round(rp_avg_ms, 4), "launches_per_step": rps["launches"] / args.steps,
                 "flops_per_launch": rp_flops, "ms_per_step": round(rps["ms"] / args.steps, 3),
                 "note": "achieved = algorithmic 2 rows 256 nc nr m flop of the launch (one product per multiply-add) / mean "
-                        "HIP-event duration of the launch; traffic = its T write (FETCH_SIZE x 2 + WRITE_SIZE, --pmc passes)"}
+                        "HIP-event duration of the launch; traffic = its T write (FETCH_SIZE x 2 + WRITE_SIZE) from the committed "
+                        "rocprofv3 --pmc passes named in traffic_source (PMC counters cannot be read from inside this process); "
+                        "useful_work_frac = (image row, value) pairs that occur / all 256 per row: frac_useful counts only those"}
         else:
             mv_bytes = mvs["bytes"] / max(1, mvs["launches"])          # algorithmic: 4 p (rows of this rank) per launch
             mv_gbs = mv_bytes / (mv_avg_ms * 1e-3) / 1e9 if mv_avg_ms > 0 else 0.0
@@ -328,22 +400,32 @@ def main():
                           "split-f16 MFMA contraction with the %d-column block)" % (ld // 32, ld),
                 "bound": "hbm", "achieved": round(mv_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(mv_gbs / PEAK_HBM_GBS, 4), "traffic": prof.get("matvec_bytes_per_launch"),
+                "traffic_source": prof.get("matvec_source", "none: no committed --pmc pass for this configuration"),
                 "avg_launch_ms": round(mv_avg_ms, 4), "launches_per_step": mvs["launches"] / args.steps,
                 "bytes_per_launch": mv_bytes, "ms_per_step": round(mvs["ms"] / args.steps, 3),
                 "note": "achieved = algorithmic 4 p rows bytes (the L_A block of this rank) / mean HIP-event duration of the "
                         "sweep kernel; the largest single-kernel share of the step"}
         line = {
-            "metric": "filtered Mpixels/sec @ 4K img, 0.5% samples",
+            "metric": "filtered Mpixels/sec @ 4K img, 0.5% samples; PSNR vs PETSc ref",
             "value": round(value, 4), "unit": "Mpixel/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32 (f32 storage and accumulation; MFMA operands split into f16 hi+lo pairs = 22 significant bits)"
+                      if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32"),
+            "data": "synthetic",
             "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g, "
                                    "no exact-zero skipping (every kernel entry enters the sums: %s)" % (size, size, args.sample_frac * 100, p, m, args.epsilon,
                                    "grid-factored forms" if info["nystroem_path"] == 1 else "entry-by-entry kernels"),
                        "N": N, "p": p, "m": m, "epsilon": args.epsilon, "outer_its": info["outer_its"],
                        "inner_its_total": info["inner_its_total"], "residual": round(info["residual"], 5),
                        "contraction": "f16 split (hi+lo), f32 accumulate" if info["contraction"] == glf.CONTRACT_F16_SPLIT else "f32 MFMA",
-                       "sharding": "pixel rows / %d ranks; L_A column blocks / %d ranks" % (n_gpus, n_gpus)},
+                       "image_crc32": "%08x" % crc,
+                       "psnr_reference": "PETSc/SLEPc are not installable here (SURVEY 8c): PSNR is against the fp64 restatement of "
+                                         "hpc/*.c, see cpu_baseline.parity_headline (this run, sampled rows) and .parity_cfg2 (whole image)",
+                       "sharding": "pixel rows / %d ranks; eigen-solve rows / %d ranks (all-reduce of inner products and Gram blocks, "
+                                   "all-gather of the operand per L_A application); collectives: %s" %
+                                   (n_gpus, n_gpus, "none" if n_gpus == 1 and not args.force_comm else
+                                    ("RCCL issued by the library" if args.comm == "rccl" else "torch.distributed callbacks"))},
             "stage_ms_rank0": stage_ms,
             "roofline": roofline,
             "eigen_sweeps": sweeps,
@@ -363,10 +445,25 @@ def main():
             }
         if batch_leg is not None:
             line["throughput_mode"] = batch_leg
+        if direct_leg is not None:
+            d_ms = direct_leg["nystroem_kernel_ms"]
+            d_tf = flops / (d_ms * 1e-3) / 1e12
+            line["direct_contraction"] = {
+                "kernel": "k_nystroem_f16s<%d,%d> (Phi = K_B^T Psi entry by entry: K_B generated in registers from LDS factor tables, "
+                          "split-f16 MFMA, f32 accumulate; GLF_NYS_PATH=direct)" % (ld // 32, 2 if ld <= 64 else 1),
+                "steps": 1, "kernel_ms": round(d_ms, 3), "step_ms": round(direct_leg["ms_total"], 3),
+                "roofline": {"bound": "mfma", "achieved": round(d_tf, 1), "peak": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
+                             "frac": round(d_tf / (PEAK_F16_MFMA_TFLOPS / 3.0), 4), "traffic": None,
+                             "flops_per_launch": flops,
+                             "note": "achieved = SURVEY 8d W_nys = 2 (N - p) p m flop / HIP-event duration of the kernel; peak = f16 "
+                                     "dense MFMA peak / 3 split products"}}
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img, info, args)
         if n_gpus == 1 and not args.no_parity and "cpu_baseline" in line:
+            if cap_run is not None:
+                line["cpu_baseline"]["parity_headline"] = parity_headline(ctx, img, cap_run, args)
             line["cpu_baseline"]["parity_cfg2"] = cpu_parity_cfg2(ctx)
+        line.pop("capture", None)
         print(json.dumps(line))
     ctx.close()
     if world > 1 or args.force_comm:

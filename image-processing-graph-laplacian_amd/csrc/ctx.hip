@@ -94,6 +94,7 @@ int glf_ctx_destroy(glf_ctx *ctx)
     for (auto &row : ctx->mv_ev)
         for (auto &e : row)
             if (e) (void)hipEventDestroy(e);
+    glf::native_comm_release(ctx);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->x0_block) (void)hipFree(ctx->x0_block);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -124,6 +125,8 @@ int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *nu
 int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm)
 {
     if (!ctx) return GLF_ERR_INVALID;
+    glf::native_comm_release(ctx); // a communicator the library created itself (glf_ctx_set_comm_rccl) is replaced
+    ctx->force_comm = false;
     if (!comm || comm->size <= 1) {
         ctx->comm = glf_comm{};
         ctx->comm.size = 1;

@@ -16,6 +16,7 @@
 // All reductions go through fixed-order f64 partial buffers => reproducible.
 #include "glf_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -413,12 +414,7 @@ static int block_matvec_f16s(glf_ctx *ctx, const float *A, int64_t lda, unsigned
                                ksplit, p_pad, row0, row1, ld, scales, Y);
     }
     GLF_LAUNCH_CHECK(ctx);
-    if (sharded) { // every rank needs the whole Y: in-place all-gather of the row blocks
-        if (!ctx->has_comm || !ctx->comm.allgather_f32) return set_error(ctx, GLF_ERR_COMM, "sharded mat-vec without allgather_f32");
-        if (ctx->comm.allgather_f32(ctx->comm.user, Y, (size_t)shard->rows_per_rank * ld) != 0)
-            return set_error(ctx, GLF_ERR_COMM, "allgather_f32 callback failed");
-    }
-    return GLF_OK;
+    return GLF_OK; // sharded: rows [row0, row1) of Y only -- the vector kernels that follow are row-sharded too
 }
 
 int start_block_cached(glf_ctx *ctx, unsigned p, unsigned m, unsigned ld, unsigned long long seed, const float **d_block)
@@ -458,6 +454,53 @@ int mv_collect(glf_ctx *ctx)
     return GLF_OK;
 }
 
+// ---- row sharding of the vector blocks (multi-GPU eigen-solve) ------------------------------------------------------
+// With a sharded operator (MatShard::rows_per_rank > 0) rank g owns rows [row0, row1) of EVERY vector block: the PCG
+// updates, Gram-Schmidt, the residual and the final normalisation touch those rows only, and what crosses xGMI is
+//   * one all-reduce of ld (or 2 ld) f64 scalars per inner product / norm (hpc/gram_schmidt.c:14-15,59: VecDot, VecNorm),
+//   * one all-reduce of the ld x ld Gram block per Gram-Schmidt / residual (hpc/inverse_power_it.c:55-72),
+//   * one all-gather of the operand block before each operator application (what PETSc's MPIDENSE MatMult does,
+//     hpc/inverse_power_it.c:167): the operator needs every row of its operand, nothing else does.
+// The blocks keep their full size on every rank (rows_per_rank * size rows) so that the all-gather runs in place.
+struct Rows {
+    unsigned r0 = 0, r1 = 0; // this rank's rows
+    bool dist = false;       // sums need an all-reduce, operator operands an all-gather
+    unsigned n() const { return r1 - r0; }
+};
+static inline Rows rows_of(unsigned p, const MatShard *sh)
+{
+    Rows r;
+    if (sh && sh->rows_per_rank) {
+        r.r0 = sh->row0;
+        r.r1 = sh->row1;
+        r.dist = true;
+    } else {
+        r.r1 = p;
+    }
+    return r;
+}
+static int allreduce_d(glf_ctx *ctx, double *d, size_t n)
+{
+    if (!ctx->has_comm || ctx->comm.allreduce_sum_f64(ctx->comm.user, d, n) != 0)
+        return set_error(ctx, GLF_ERR_COMM, "allreduce_sum_f64 callback failed");
+    return GLF_OK;
+}
+static int allreduce_f(glf_ctx *ctx, float *d, size_t n)
+{
+    if (!ctx->has_comm || ctx->comm.allreduce_sum_f32(ctx->comm.user, d, n) != 0)
+        return set_error(ctx, GLF_ERR_COMM, "allreduce_sum_f32 callback failed");
+    return GLF_OK;
+}
+// every rank's row block of V -> all ranks (in place; V holds rows_per_rank * size rows)
+static int allgather_rows(glf_ctx *ctx, float *V, const MatShard *sh, unsigned ld)
+{
+    if (!ctx->has_comm || !ctx->comm.allgather_f32) return set_error(ctx, GLF_ERR_COMM, "sharded eigen-solve without allgather_f32");
+    if (ctx->comm.allgather_f32(ctx->comm.user, V, (size_t)sh->rows_per_rank * ld) != 0)
+        return set_error(ctx, GLF_ERR_COMM, "allgather_f32 callback failed");
+    return GLF_OK;
+}
+
+// Y[rows of this rank] = A X; X must hold all p rows (sharded callers all-gather it first)
 int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const float *X, float *Y, unsigned ld,
                  const MatShard *shard)
 {
@@ -470,11 +513,6 @@ int block_matvec(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, const fl
         GLF_TRY(grid_op_apply(ctx, shard->grid, X, Y, ld, shard->grid_alpha, shard->grid_degree, row0, row1, shard->grid_window));
         GLF_HIP(ctx, hipEventRecord(ctx->mv_ev[1][ctx->mv_pending], ctx->stream));
         ++ctx->mv_pending;
-        if (sharded) {
-            if (!ctx->has_comm || !ctx->comm.allgather_f32) return set_error(ctx, GLF_ERR_COMM, "sharded mat-vec without allgather_f32");
-            if (ctx->comm.allgather_f32(ctx->comm.user, Y, (size_t)shard->rows_per_rank * ld) != 0)
-                return set_error(ctx, GLF_ERR_COMM, "allgather_f32 callback failed");
-        }
         return GLF_OK;
     }
     if (sharded && ctx->contraction != GLF_CONTRACT_F16_SPLIT)
@@ -553,6 +591,20 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__
     double s[1];
     wg_sum_partials<1>(partial, nblk, (unsigned)ncols, s, sh);
     if ((int)threadIdx.x < ncols) out[threadIdx.x] = s[0];
+}
+
+// sums[v * ld + c] = sum_blk partial[(blk * NV + v) * ld + c]: the local sums of a row-sharded reduction, all-reduced by the
+// host before the second-level kernel consumes them as ONE block (nblk = 1)
+template <int NV>
+__global__ __launch_bounds__(256) void k_sum_partials_nv(const double *__restrict__ partial, int nblk, unsigned ld,
+                                                          double *__restrict__ sums)
+{
+    __shared__ double sh[NV * 256];
+    double s[NV];
+    wg_sum_partials<NV>(partial, nblk, ld, s, sh);
+    if (threadIdx.x < ld)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sums[v * ld + threadIdx.x] = s[v];
 }
 
 // Block-level column reduction helper: 256 threads, column = t % ld, row lane = t / ld.
@@ -735,23 +787,26 @@ __global__ void k_diag_inv(const float *__restrict__ A, int64_t lda, unsigned p,
 
 struct CgWork {
     DevBuf<float> R, P, AP, Xs, dinv;
-    DevBuf<double> partial, scal;
+    DevBuf<double> partial, scal, sums;
     DevBuf<int> flags;
     CgScalars s{};
     int nblk = 0;
+    Rows rows;                // the rows of the vector blocks this rank updates (all of them unless the solve is sharded)
     int *h_nactive = nullptr; // in the context's pinned page
     const MatShard *shard = nullptr;
     int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
     {
         shard = sh;
+        rows = rows_of(p, sh);
         const size_t n = (size_t)vec_rows(p, sh, ctx->comm.size) * ld;
         GLF_TRY(R.alloc(ctx, n));
         GLF_TRY(P.alloc(ctx, n));
         GLF_TRY(AP.alloc(ctx, n));
         GLF_TRY(Xs.alloc(ctx, n));
         GLF_TRY(dinv.alloc(ctx, p));
-        nblk = (int)ceil_div(p, RED_ROWS);
-        GLF_TRY(partial.alloc(ctx, (size_t)nblk * 2 * ld));
+        nblk = (int)ceil_div(rows.n(), RED_ROWS);
+        GLF_TRY(partial.alloc(ctx, (size_t)std::max(1, nblk) * 2 * ld));
+        GLF_TRY(sums.alloc(ctx, (size_t)2 * ld));
         GLF_TRY(scal.alloc(ctx, (size_t)4 * ld));
         GLF_TRY(flags.alloc(ctx, ld + 1));
         for (float *q : {R.p, P.p, AP.p, Xs.p}) GLF_HIP(ctx, hipMemsetAsync(q, 0, n * sizeof(float), ctx->stream));
@@ -772,29 +827,53 @@ struct CgWork {
 static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, unsigned p, float *XB, unsigned m,
                           unsigned ld, double rtol, int max_it, int *iters)
 {
-    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const int nblk = w.nblk;
-    const unsigned nelem_blocks = (unsigned)ceil_div((int64_t)p * ld, 256);
+    const Rows rows = w.rows;
+    const unsigned nloc = rows.n();
+    const size_t off = (size_t)rows.r0 * ld; // first element of this rank's rows in every vector block
+    const unsigned nelem_blocks = (unsigned)ceil_div((int64_t)nloc * ld, 256);
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_cg_init, dim3(nblk), dim3(256), 0, st, XB, w.dinv.p, w.R.p, w.P.p, w.Xs.p, p, ld, w.partial.p);
-    hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, m, w.s);
+    // second-level reductions: the per-block partial sums of this rank, or (sharded) their all-reduced totals as one block
+    auto reduce2 = [&](int nv, const double **src, int *src_blk) -> int {
+        *src = w.partial.p;
+        *src_blk = nblk;
+        if (!rows.dist) return GLF_OK;
+        if (nv == 1) hipLaunchKernelGGL(k_sum_partials_nv<1>, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.sums.p);
+        else hipLaunchKernelGGL(k_sum_partials_nv<2>, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.sums.p);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_TRY(allreduce_d(ctx, w.sums.p, (size_t)nv * ld));
+        *src = w.sums.p;
+        *src_blk = 1;
+        return GLF_OK;
+    };
+    const double *src = nullptr;
+    int src_blk = 0;
+    if (nblk > 0)
+        hipLaunchKernelGGL(k_cg_init, dim3(nblk), dim3(256), 0, st, XB + off, w.dinv.p + rows.r0, w.R.p + off, w.P.p + off, w.Xs.p + off,
+                           nloc, ld, w.partial.p);
+    GLF_TRY(reduce2(2, &src, &src_blk));
+    hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, st, src, src_blk, ld, m, w.s);
     GLF_LAUNCH_CHECK(ctx);
     int it = 0;
     GLF_HIP(ctx, hipStreamSynchronize(st));
     while (*(volatile int *)w.h_nactive > 0 && it < max_it) {
         ++it;
+        if (rows.dist) GLF_TRY(allgather_rows(ctx, w.P.p, w.shard, ld)); // the operator needs every row of its operand
         GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld, w.shard));
-        hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p, w.AP.p, p, ld, w.partial.p);
-        hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.s);
-        hipLaunchKernelGGL(k_cg_update, dim3(nblk), dim3(256), 0, st, w.Xs.p, w.R.p, w.P.p, w.AP.p, w.dinv.p, p, ld, w.s,
-                           w.partial.p);
-        hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, rtol * rtol, w.s);
-        hipLaunchKernelGGL(k_cg_pupdate, dim3(nelem_blocks), dim3(256), 0, st, w.P.p, w.R.p, w.dinv.p, p, ld, w.s);
+        if (nblk > 0) hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p + off, w.AP.p + off, nloc, ld, w.partial.p);
+        GLF_TRY(reduce2(1, &src, &src_blk));
+        hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, st, src, src_blk, ld, w.s);
+        if (nblk > 0)
+            hipLaunchKernelGGL(k_cg_update, dim3(nblk), dim3(256), 0, st, w.Xs.p + off, w.R.p + off, w.P.p + off, w.AP.p + off,
+                               w.dinv.p + rows.r0, nloc, ld, w.s, w.partial.p);
+        GLF_TRY(reduce2(2, &src, &src_blk));
+        hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, st, src, src_blk, ld, rtol * rtol, w.s);
+        if (nelem_blocks > 0)
+            hipLaunchKernelGGL(k_cg_pupdate, dim3(nelem_blocks), dim3(256), 0, st, w.P.p + off, w.R.p + off, w.dinv.p + rows.r0, nloc, ld, w.s);
         GLF_LAUNCH_CHECK(ctx);
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }
-    (void)p32;
-    GLF_HIP(ctx, hipMemcpyAsync(XB, w.Xs.p, sizeof(float) * (size_t)p * ld, hipMemcpyDeviceToDevice, st));
+    if (nloc > 0) GLF_HIP(ctx, hipMemcpyAsync(XB + off, w.Xs.p + off, sizeof(float) * (size_t)nloc * ld, hipMemcpyDeviceToDevice, st));
     if (iters) *iters = it;
     return (*w.h_nactive > 0) ? set_error(ctx, GLF_ERR_NOCONV, "block PCG: %d columns unconverged after %d iterations",
                                           *w.h_nactive, it)
@@ -1232,7 +1311,7 @@ struct GsFusedWork {
         n = n_;
         ld = ld_;
         nchunks = (int)ceil_div(n, GSF_ROWS);
-        GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
+        GLF_TRY(Gpart.alloc(ctx, (size_t)std::max(1, nchunks) * ld * ld));
         GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
         GLF_TRY(Tn.alloc(ctx, (size_t)ld * ld));
         if (ld > 64) GLF_TRY(S.alloc(ctx, (size_t)ld * ld));
@@ -1266,22 +1345,30 @@ struct GsWork {
 };
 
 // returns GLF_OK with *fell_back = 1 when the device found V too ill-conditioned (X untouched)
-static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, unsigned n, unsigned m, unsigned ld,
+// rows: this rank's rows of X (X points at row 0 of the whole block); dist: the Gram block is all-reduced
+static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, Rows rows, unsigned m, unsigned ld,
                                     double *d_norms, int *fell_back)
 {
     hipStream_t st = ctx->stream;
+    const unsigned n = rows.n();
+    float *Xl = X + (size_t)rows.r0 * ld;
     GLF_TRY(f.init(ctx, n, ld));
     const int tile = ld >= 64 ? 64 : 32, mb = (int)ld / tile;
-    if (tile == 64)
-        hipLaunchKernelGGL((k_gsf_gram<64>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
-    else
-        hipLaunchKernelGGL((k_gsf_gram<32>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, X, n, ld, f.Gpart.p);
+    if (f.nchunks > 0) {
+        if (tile == 64)
+            hipLaunchKernelGGL((k_gsf_gram<64>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, Xl, n, ld, f.Gpart.p);
+        else
+            hipLaunchKernelGGL((k_gsf_gram<32>), dim3(f.nchunks, mb * mb), dim3(256), 0, st, Xl, n, ld, f.Gpart.p);
+    }
     hipLaunchKernelGGL(k_gsf_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, f.Gpart.p, f.nchunks, ld, tile, f.G.p);
+    GLF_LAUNCH_CHECK(ctx);
+    if (rows.dist) GLF_TRY(allreduce_d(ctx, f.G.p, (size_t)ld * ld)); // G = V^T V over all ranks' rows (hpc/gram_schmidt.c:14-15)
     if (ld <= 64)
         hipLaunchKernelGGL(k_gsf_recur_lds, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.Tn.p, d_norms, f.flag.p, f.h_flag);
     else
         hipLaunchKernelGGL(k_gsf_recur_global, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.S.p, f.Tn.p, d_norms, f.flag.p, f.h_flag);
-    hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, GSF_APPLY_TILE / ld)), dim3(256), 0, st, X, n, ld, m, f.Tn.p, f.flag.p);
+    if (n > 0)
+        hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, GSF_APPLY_TILE / ld)), dim3(256), 0, st, Xl, n, ld, m, f.Tn.p, f.flag.p);
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(st));
     *fell_back = *(volatile int *)f.h_flag;
@@ -1308,18 +1395,28 @@ static int orthonormalise_seq_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n,
 
 // OrthonormaliseVecs (hpc/gram_schmidt.c:29-64): the Gram-matrix form unless GLF_GS=seq or the vectors are too
 // ill-conditioned for it. Either way w.norms holds the post-GS norms |u_k|.
-static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld)
+// n = rows of the whole block; rows = the rows this rank updates. A sharded call that has to fall back to the column
+// sweep first all-gathers X (shard != nullptr) and then sweeps all n rows on every rank (identical results everywhere):
+// *replicated tells the caller that X is whole and valid on every rank afterwards.
+static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, unsigned m, unsigned ld, Rows rows = Rows{},
+                              const MatShard *shard = nullptr, bool *replicated = nullptr)
 {
+    if (!rows.dist) rows.r1 = n, rows.r0 = 0;
+    if (replicated) *replicated = false;
     const char *mode = std::getenv("GLF_GS");
     w.last_fused = false;
     if (!(mode && std::strcmp(mode, "seq") == 0)) {
         int fell_back = 0;
-        GLF_TRY(orthonormalise_fused_dev(ctx, w.fused, X, n, m, ld, w.norms.p, &fell_back));
+        GLF_TRY(orthonormalise_fused_dev(ctx, w.fused, X, rows, m, ld, w.norms.p, &fell_back));
         if (!fell_back) {
             w.last_fused = true;
             return GLF_OK;
         }
         if (std::getenv("GLF_VERBOSE")) fprintf(stderr, "[glf] Gram-Schmidt: ill-conditioned block, column-by-column sweep\n");
+    }
+    if (rows.dist) {
+        GLF_TRY(allgather_rows(ctx, X, shard, ld));
+        if (replicated) *replicated = true;
     }
     return orthonormalise_seq_dev(ctx, w, X, n, m, ld);
 }
@@ -1335,13 +1432,26 @@ int orthonormalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, 
     return GLF_OK;
 }
 
-static int normalise_dev(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *d_partial, double *d_norms)
+// NormaliseVecs (hpc/gram_schmidt.c:66-77) on this rank's rows; sharded: the squared column norms are all-reduced
+static int normalise_dev(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, double *d_partial, double *d_norms,
+                         Rows rows = Rows{}, double *d_sums = nullptr)
 {
-    const int nblk = (int)ceil_div(n, RED_ROWS);
-    hipLaunchKernelGGL(k_col_sumsq, dim3(nblk), dim3(256), 0, ctx->stream, X, n, ld, d_partial);
-    hipLaunchKernelGGL(k_norms_from_partials, dim3(1), dim3(256), 0, ctx->stream, d_partial, nblk, ld, d_norms);
-    hipLaunchKernelGGL(k_scale_all, dim3((unsigned)ceil_div((int64_t)n * ld, 256)), dim3(256), 0, ctx->stream, X, n, ld, m,
-                       d_norms);
+    if (!rows.dist) rows.r1 = n, rows.r0 = 0;
+    const unsigned nloc = rows.n();
+    float *Xl = X + (size_t)rows.r0 * ld;
+    const int nblk = (int)ceil_div(nloc, RED_ROWS);
+    hipStream_t st = ctx->stream;
+    if (nblk > 0) hipLaunchKernelGGL(k_col_sumsq, dim3(nblk), dim3(256), 0, st, Xl, nloc, ld, d_partial);
+    if (rows.dist) {
+        hipLaunchKernelGGL(k_sum_partials_nv<1>, dim3(1), dim3(256), 0, st, d_partial, nblk, ld, d_sums);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_TRY(allreduce_d(ctx, d_sums, ld));
+        hipLaunchKernelGGL(k_norms_from_partials, dim3(1), dim3(256), 0, st, d_sums, 1, ld, d_norms);
+    } else {
+        hipLaunchKernelGGL(k_norms_from_partials, dim3(1), dim3(256), 0, st, d_partial, nblk, ld, d_norms);
+    }
+    if (nloc > 0)
+        hipLaunchKernelGGL(k_scale_all, dim3((unsigned)ceil_div((int64_t)nloc * ld, 256)), dim3(256), 0, st, Xl, nloc, ld, m, d_norms);
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
 }
@@ -1364,20 +1474,23 @@ int normalise(glf_ctx *ctx, float *X, unsigned n, unsigned m, unsigned ld, doubl
 constexpr int GRAM_ROWS = 256; // rows per Gram workgroup chunk
 
 // Gpart[chunk][a][b] = sum_{i in chunk} X[i][a] * Y[i][b]; one wave per 32x32 (a,b) tile.
-__global__ __launch_bounds__(64) void k_gram(const float *__restrict__ X, const float *__restrict__ Y, unsigned p32,
+__global__ __launch_bounds__(64) void k_gram(const float *__restrict__ X, const float *__restrict__ Y, unsigned n,
                                               unsigned ld, float *__restrict__ Gpart)
 {
     const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
     const int mb = ld / 32;
     const int ta = blockIdx.x / mb, tb = blockIdx.x % mb;
     const unsigned r0 = blockIdx.y * GRAM_ROWS;
-    const unsigned r1 = min(r0 + GRAM_ROWS, p32);
+    const unsigned r1 = min(r0 + GRAM_ROWS, n);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (unsigned i = r0 + half; i < r1; i += 2) // p32 even: both halves stay in range together
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[(size_t)i * ld + 32 * ta + l31], Y[(size_t)i * ld + 32 * tb + l31], acc,
-                                                   0, 0, 0);
+    for (unsigned i0 = r0; i0 < r1; i0 += 2) { // the two halves of the wave supply rows i0 and i0 + 1 (zeros past the last row:
+        const unsigned i = i0 + half;          // with an odd count the next row belongs to another rank's block)
+        const bool ok = i < r1;
+        const float a = ok ? X[(size_t)i * ld + 32 * ta + l31] : 0.f, b = ok ? Y[(size_t)i * ld + 32 * tb + l31] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
     float *g = Gpart + (size_t)blockIdx.y * ld * ld;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1442,40 +1555,57 @@ __global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, cons
 
 struct ResWork {
     DevBuf<float> AX, Gpart, G;
-    DevBuf<double> partial;
+    DevBuf<double> partial, sums;
     double *h_sums = nullptr; // in the context's pinned page: the last reduction kernel writes into it (no D2H copy launch)
     int nchunks = 0;
+    Rows rows;
     const MatShard *shard = nullptr;
     int init(glf_ctx *ctx, unsigned p, unsigned ld, const MatShard *sh = nullptr)
     {
         shard = sh;
-        const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
+        rows = rows_of(p, sh);
         const size_t vr = vec_rows(p, sh, ctx->comm.size);
-        nchunks = (int)ceil_div(p32, GRAM_ROWS);
+        nchunks = (int)ceil_div(rows.n(), GRAM_ROWS);
         GLF_TRY(AX.alloc(ctx, vr * ld));
         GLF_HIP(ctx, hipMemsetAsync(AX.p, 0, sizeof(float) * vr * ld, ctx->stream));
-        GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * ld * ld));
+        GLF_TRY(Gpart.alloc(ctx, (size_t)std::max(1, nchunks) * ld * ld));
         GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
-        GLF_TRY(partial.alloc(ctx, (size_t)ceil_div(p, RED_ROWS) * ld));
+        GLF_TRY(partial.alloc(ctx, (size_t)std::max<int64_t>(1, ceil_div(rows.n(), RED_ROWS)) * ld));
+        GLF_TRY(sums.alloc(ctx, ld));
         if (!ctx_pinned(ctx) || ld > 256) return set_error(ctx, GLF_ERR_NOMEM, "pinned host page");
         h_sums = reinterpret_cast<double *>(ctx_pinned(ctx) + PINNED_SUMS);
         return GLF_OK;
     }
 };
 
-// ax_ready: w.AX already holds A X (derived from the PCG state, see inverse_power_iteration) -- no sweep over L_A
-static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, unsigned p, const float *X, unsigned m,
+// ax_ready: w.AX already holds (this rank's rows of) A X, derived from the PCG state (see inverse_power_iteration) -- no
+// sweep over L_A. Sharded: X^T A X (ld x ld) and the ld squared column norms are all-reduced (hpc/inverse_power_it.c:55-72).
+static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, unsigned p, float *X, unsigned m,
                         unsigned ld, double *h_out, bool ax_ready = false)
 {
-    const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
-    const int nblk = (int)ceil_div(p, RED_ROWS);
+    const Rows rows = w.rows;
+    const unsigned nloc = rows.n();
+    const size_t off = (size_t)rows.r0 * ld;
+    const int nblk = (int)ceil_div(nloc, RED_ROWS);
     hipStream_t st = ctx->stream;
-    if (!ax_ready) GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld, w.shard));
+    if (!ax_ready) {
+        if (rows.dist) GLF_TRY(allgather_rows(ctx, X, w.shard, ld)); // the operator needs every row of X
+        GLF_TRY(block_matvec(ctx, A, lda, p, X, w.AX.p, ld, w.shard));
+    }
     const int mb = ld / 32;
-    hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X, w.AX.p, p32, ld, w.Gpart.p);
+    if (w.nchunks > 0) hipLaunchKernelGGL(k_gram, dim3(mb * mb, w.nchunks), dim3(64), 0, st, X + off, w.AX.p + off, nloc, ld, w.Gpart.p);
     hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
-    hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X, w.AX.p, w.G.p, p, ld, m, w.partial.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, w.partial.p, nblk, (int)ld, w.h_sums);
+    GLF_LAUNCH_CHECK(ctx);
+    if (rows.dist) GLF_TRY(allreduce_f(ctx, w.G.p, (size_t)ld * ld));
+    if (nblk > 0) hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X + off, w.AX.p + off, w.G.p, nloc, ld, m, w.partial.p);
+    if (rows.dist) {
+        hipLaunchKernelGGL(k_sum_partials_nv<1>, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.sums.p);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_TRY(allreduce_d(ctx, w.sums.p, ld));
+        GLF_HIP(ctx, hipMemcpyAsync(w.h_sums, w.sums.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
+    } else {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, w.partial.p, nblk, (int)ld, w.h_sums);
+    }
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(st));
     double ss = 0.0;
@@ -1539,6 +1669,10 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     GLF_TRY(cg.init(ctx, p, ld, shard));
     ResWork rs;
     GLF_TRY(rs.init(ctx, p, ld, shard));
+    // Sharded solve (see Rows above): every vector kernel below touches this rank's rows [rows.r0, rows.r1) only.
+    const Rows rows = rows_of(p, shard);
+    const unsigned nloc = rows.n();
+    const size_t off = (size_t)rows.r0 * ld, nloc_ld = (size_t)nloc * ld;
     if (d_dinv) // Jacobi preconditioner supplied by the caller (a sharded A does not hold the whole diagonal)
         GLF_HIP(ctx, hipMemcpyAsync(cg.dinv.p, d_dinv, sizeof(float) * p, hipMemcpyDeviceToDevice, st));
     else if (shard && shard->rows_per_rank)
@@ -1550,7 +1684,8 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     GLF_TRY(mv_collect(ctx));
     const int mv_count0 = ctx->mv_count;
     const double mv_ms0 = ctx->mv_ms, mv_bytes0 = ctx->mv_bytes;
-    GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :95
+    bool replicated = false;
+    GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld, rows, shard, &replicated)); // :95
     // The reference leaves X_k_before_orth unset when the loop never runs (:97-101); define it.
     GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
     double r_norm = 0.0;
@@ -1568,21 +1703,22 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         }
         ++it;
         int inner = 0;
-        const size_t npl = (size_t)p * ld;
-        if (derive_ax) GLF_HIP(ctx, hipMemcpyAsync(rs.AX.p, X.p, sizeof(float) * npl, hipMemcpyDeviceToDevice, st)); // B
+        if (derive_ax && nloc) GLF_HIP(ctx, hipMemcpyAsync(rs.AX.p + off, X.p + off, sizeof(float) * nloc_ld, hipMemcpyDeviceToDevice, st)); // B
         GLF_TRY(block_pcg_work(ctx, cg, A, lda, p, X.p, m, ld, inner_rtol, 10 * (int)p + 100, &inner)); // :165-168
         inner_total += inner;
-        GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st)); // CopyVecs :171
+        if (nloc) GLF_HIP(ctx, hipMemcpyAsync(Xb.p + off, X.p + off, sizeof(float) * nloc_ld, hipMemcpyDeviceToDevice, st)); // CopyVecs :171
         bool ax_ready = derive_ax;
-        if (derive_ax) // A Y = B - R
-            hipLaunchKernelGGL(k_sub_inplace, dim3((unsigned)ceil_div((int64_t)npl, 256)), dim3(256), 0, st, rs.AX.p, cg.R.p, npl);
+        if (derive_ax && nloc) // A Y = B - R
+            hipLaunchKernelGGL(k_sub_inplace, dim3((unsigned)ceil_div((int64_t)nloc_ld, 256)), dim3(256), 0, st, rs.AX.p + off, cg.R.p + off, nloc_ld);
         if (it % opti_gs == 0) {
-            GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :174-177
-            if (ax_ready && gs.last_fused) // A X_new = (A Y) Tn
-                hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(p, GSF_APPLY_TILE / ld)), dim3(256), 0, st, rs.AX.p, p, ld, m,
-                                   gs.fused.Tn.p, gs.fused.flag.p);
-            else
+            GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld, rows, shard, &replicated)); // :174-177
+            if (ax_ready && gs.last_fused) { // A X_new = (A Y) Tn
+                if (nloc)
+                    hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(nloc, GSF_APPLY_TILE / ld)), dim3(256), 0, st, rs.AX.p + off, nloc, ld,
+                                       m, gs.fused.Tn.p, gs.fused.flag.p);
+            } else {
                 ax_ready = false; // column-by-column sweep: no triangular map at hand
+            }
         }
         GLF_LAUNCH_CHECK(ctx);
         GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm, ax_ready)); // :180
@@ -1590,7 +1726,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
             fprintf(stderr, "[glf rank %d] outer iteration %d: %d block-CG steps, residual %.9g\n", ctx->comm.rank, it, inner, r_norm);
     }
     if (opti_gs != 1 && (it % opti_gs) != 0)
-        GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld)); // :183-186
+        GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld, rows, shard, &replicated)); // :183-186
 
     if (h_eigvals) { // eigenvalues = 1 / norms, :204
         std::vector<double> nr(m);
@@ -1599,7 +1735,8 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         for (unsigned j = 0; j < m; ++j) h_eigvals[j] = 1.0 / nr[j];
     }
     if (d_eigvecs) { // NormaliseVecs(X_k_before_orth), :230
-        GLF_TRY(normalise_dev(ctx, Xb.p, p, m, ld, gs.partial.p, gs.norms.p));
+        GLF_TRY(normalise_dev(ctx, Xb.p, p, m, ld, gs.partial.p, gs.norms.p, rows, cg.sums.p));
+        if (rows.dist) GLF_TRY(allgather_rows(ctx, Xb.p, shard, ld)); // every rank extends with the whole Phi_A (hpc/nystroem.c:41)
         GLF_HIP(ctx, hipMemcpyAsync(d_eigvecs, Xb.p, sizeof(float) * n_out, hipMemcpyDeviceToDevice, st));
     }
     GLF_HIP(ctx, hipStreamSynchronize(st));

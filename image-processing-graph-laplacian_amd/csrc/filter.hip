@@ -75,7 +75,7 @@ int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0
 template <int LD>
 __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict__ img, const float *__restrict__ phi,
                                                        int64_t pix0, int64_t pix1, const float *__restrict__ w, float gain,
-                                                       uint8_t *__restrict__ out, float *__restrict__ zf)
+                                                       uint8_t *__restrict__ out, float *__restrict__ zf, float *__restrict__ corr)
 {
     constexpr int LPP = LD / 4;       // lanes per pixel (8 .. 64)
     constexpr int PPB = 256 / LPP;    // pixels per block pass
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
         if (q == 0) {
             float z = fmaf(gain, s, (float)img[px]); // MatAXPY(z, 3.0, Lapl_y), hpc/display.c:73
             if (zf) zf[px] = z;
+            if (corr) corr[px - pix0] = gain * s;    // the correction z - y alone (z ~ 100 in f32 resolves it to 4e-6 only)
             z = z > 255.f ? 255.f : z;               // AboveXSetY(z, 255, 255), :76
             z = z > 0.f ? z : 0.f;                   // negative -> 0 (survey quirk Q4; also maps NaN to 0)
             out[px] = (uint8_t)z;                    // (png_byte) cast = truncation, hpc/utils.c:525
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
 }
 
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1, unsigned /*m*/,
-                 unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf)
+                 unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf, float *d_corr)
 {
     if (!valid_ld(ld) || pix0 > pix1) return set_error(ctx, GLF_ERR_INVALID, "apply_filter: ld=%u", ld);
     if (pix0 == pix1) return GLF_OK;
@@ -106,10 +107,10 @@ int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t
     if (nblk > 8192) nblk = 8192; // grid-stride the rest
     dim3 grid((unsigned)nblk), block(256);
     switch (ld) {
-    case 32: hipLaunchKernelGGL(k_apply_filter<32>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
-    case 64: hipLaunchKernelGGL(k_apply_filter<64>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
-    case 128: hipLaunchKernelGGL(k_apply_filter<128>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
-    case 256: hipLaunchKernelGGL(k_apply_filter<256>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf); break;
+    case 32: hipLaunchKernelGGL(k_apply_filter<32>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
+    case 64: hipLaunchKernelGGL(k_apply_filter<64>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
+    case 128: hipLaunchKernelGGL(k_apply_filter<128>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
+    case 256: hipLaunchKernelGGL(k_apply_filter<256>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
     }
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;

@@ -22,6 +22,8 @@ struct glf_pool_block {
     bool in_use;
 };
 
+struct glf_native_comm; // comm.hip: RCCL / loopback communicator owned by a context
+
 struct glf_ctx {
     std::vector<glf_pool_block> pool;
     int device = 0;
@@ -29,6 +31,8 @@ struct glf_ctx {
     bool owns_stream = false;
     glf_comm comm{};
     bool has_comm = false;
+    glf_native_comm *native = nullptr; // set by glf_ctx_set_comm_rccl / glf_multi_create: the library's own collectives
+    bool force_comm = false;           // run the collectives even on a one-rank world (tests of the N > 1 plumbing)
     char last_error[512] = {0};
     hipDeviceProp_t prop{};
     // reusable events for stage timing
@@ -110,6 +114,7 @@ inline bool valid_ld(unsigned ld) { return ld == 32 || ld == 64 || ld == 128 || 
 constexpr size_t POOL_GUARD_BYTES = 4096;            // debug pool: canary bytes after every block
 constexpr int POOL_CANARY = 0xA5;
 // poison: the block holds floating-point data (debug pool: handed out filled with NaN; integer blocks with zeros)
+void native_comm_release(glf_ctx *ctx);              // comm.hip
 void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan = false); // nullptr on failure (last_error set)
 void pool_put(glf_ctx *ctx, void *ptr);              // back to the pool
 void pool_forget(glf_ctx *ctx, void *ptr);           // ownership leaves the pool (caller hipFree's it)
@@ -315,6 +320,6 @@ int permute_rows(glf_ctx *ctx, const float *d_in, float *d_out, int64_t N, unsig
 int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0, int64_t pix1, unsigned m,
             unsigned ld, double *d_c);
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1,
-                 unsigned m, unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf);
+                 unsigned m, unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf, float *d_corr = nullptr);
 
 } // namespace glf

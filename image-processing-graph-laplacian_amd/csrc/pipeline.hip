@@ -400,7 +400,8 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
             GLF_HIP(ctx, hipMemcpyAsync(cap->h_degree, deg.p, sizeof(double) * p, hipMemcpyDeviceToHost, st));
             GLF_HIP(ctx, hipStreamSynchronize(st));
         }
-        if ((cap->d_phi_A && cap->phi_A_floats < (size_t)p32 * ld) || (cap->d_phi && cap->phi_floats < (size_t)(pix1 - pix0) * ld))
+        if ((cap->d_phi_A && cap->phi_A_floats < (size_t)p32 * ld) || (cap->d_phi && cap->phi_floats < (size_t)(pix1 - pix0) * ld) ||
+            (cap->d_corr && cap->corr_floats < (size_t)(pix1 - pix0)))
             return set_error(ctx, GLF_ERR_INVALID, "glf_capture: phi_A needs %zu floats, phi %zu", (size_t)p32 * ld, (size_t)(pix1 - pix0) * ld);
     }
     // ---- Laplacian ---------------------------------------------------------------------------
@@ -537,7 +538,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         GLF_HIP(ctx, hipMemcpyAsync(w.p, hw.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }
-    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, opt.gain, d_out, d_zf));
+    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, opt.gain, d_out, d_zf, cap ? cap->d_corr : nullptr));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
     GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
     GLF_HIP(ctx, hipEventElapsedTime(&S.ms_affinity, ctx->ev[0], ctx->ev[1]));

@@ -34,11 +34,14 @@ MAT_DENSE, MAT_DIAG, MAT_KERNEL_B = 0, 1, 2
 ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
 KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL = 0, 1, 2
 CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
+MULTI_RCCL, MULTI_LOOPBACK = 0, 1
+RCCL_ID_BYTES = 128
 
 # every symbol include/glf.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
-    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
+    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_rccl_unique_id", "glf_ctx_set_comm_rccl", "glf_multi_create", "glf_multi_destroy",
+    "glf_multi_size", "glf_multi_ctx", "glf_multi_last_error", "glf_multi_image_processing", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
     "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_mat_get_column", "glf_Sampling",
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
@@ -88,7 +91,8 @@ class Stats(C.Structure):
 
 class Capture(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("ld", C.c_uint32), ("d_phi_A", C.c_void_p), ("phi_A_floats", C.c_size_t),
-                ("d_phi", C.c_void_p), ("phi_floats", C.c_size_t), ("h_c", C.c_void_p), ("h_degree", C.c_void_p)]
+                ("d_phi", C.c_void_p), ("phi_floats", C.c_size_t), ("h_c", C.c_void_p), ("h_degree", C.c_void_p),
+                ("d_corr", C.c_void_p), ("corr_floats", C.c_size_t)]
 
 
 ALLREDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -105,6 +109,9 @@ _lib.glf_strerror.restype = C.c_char_p
 _lib.glf_ctx_last_error.restype = C.c_char_p
 _lib.glf_ctx_last_error.argtypes = [C.c_void_p]
 _lib.glf_host_free.restype = None
+_lib.glf_multi_ctx.restype = C.c_void_p
+_lib.glf_multi_last_error.restype = C.c_char_p
+_lib.glf_multi_last_error.argtypes = [C.c_void_p]
 _lib.glf_options_default.restype = None
 
 
@@ -216,6 +223,66 @@ def make_comm(rank, size, allreduce, allgather=None):
     return Comm(rank, size, ALLREDUCE_F32(wrap(allreduce, False)), ALLREDUCE_F64(wrap(allreduce, True)), ag, None)
 
 
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (one rank calls this, every rank passes the bytes to Context.set_comm_rccl)."""
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    rc = _lib.glf_rccl_unique_id(buf, C.c_size_t(RCCL_ID_BYTES))
+    if rc != OK:
+        raise GlfError(rc, "glf_rccl_unique_id")
+    return buf.raw
+
+
+class Multi:
+    """glf_multi: ONE process driving n GPU ranks (one context + one host thread each), the C host's -ngpu N.
+    backend MULTI_RCCL: ncclCommInitAll over distinct devices; MULTI_LOOPBACK: host-staged collectives, ranks may share a
+    device (tests on a one-GPU box)."""
+
+    def __init__(self, n, devices=None, backend=MULTI_LOOPBACK):
+        self._w = C.c_void_p()
+        devs = (C.c_int * n)(*devices) if devices is not None else None
+        rc = _lib.glf_multi_create(C.byref(self._w), C.c_int(n), devs, C.c_int(backend))
+        if rc != OK:
+            raise GlfError(rc, "glf_multi_create(%d, backend %d)" % (n, backend))
+        self.n = n
+
+    def close(self):
+        if self._w:
+            _lib.glf_multi_destroy(self._w)
+            self._w = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_contraction(self, mode):
+        for r in range(self.n):
+            rc = _lib.glf_ctx_set_contraction(C.c_void_p(_lib.glf_multi_ctx(self._w, C.c_int(r))), C.c_int(mode))
+            if rc != OK:
+                raise GlfError(rc)
+
+    def image_processing(self, img, opt=None, want_float=False):
+        """Host image in, host image out (glf_multi_image_processing): (out u8 [H, W], zf f32 [H, W] or None, per-rank infos)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        opt = opt or default_options()
+        out = np.zeros((h, w), dtype=np.uint8)
+        zf = np.zeros((h, w), dtype=np.float32) if want_float else None
+        lam = np.zeros(4096, dtype=np.float64)
+        stats = (Stats * self.n)()
+        rc = _lib.glf_multi_image_processing(self._w, C.byref(opt), img.ctypes.data_as(C.c_void_p), C.c_int(w), C.c_int(h),
+                                             out.ctypes.data_as(C.c_void_p), zf.ctypes.data_as(C.c_void_p) if want_float else None,
+                                             lam.ctypes.data_as(C.c_void_p), stats)
+        if rc != OK:
+            raise GlfError(rc, "glf_multi_image_processing: " + _lib.glf_multi_last_error(self._w).decode())
+        infos = [dict(p=s.p, m=s.m, alpha=s.alpha, outer_its=s.eig.outer_its, inner_its_total=s.eig.inner_its_total,
+                      residual=s.eig.residual, row0=s.row0, row1=s.row1, ms_total=s.ms_total, ms_eigen=s.ms_eigen,
+                      ms_nystroem=s.ms_nystroem, ms_affinity=s.ms_affinity, nystroem_path=s.nystroem_path,
+                      matvec_path=s.matvec_path, eigvals=lam[:s.m].copy()) for s in stats]
+        return out, zf, infos
+
+
 # ---- device context --------------------------------------------------------------------
 
 class Context:
@@ -270,6 +337,15 @@ class Context:
         return dict(name=name.value.decode(), num_cus=cus.value, total_mem=mem.value)
 
     # -- collectives ---------------------------------------------------------------------------
+    def set_comm_rccl(self, rank, size, unique_id, force=False):
+        """The library's own RCCL collectives on this context's stream (glf_ctx_set_comm_rccl: ncclCommInitRank, collective
+        over all `size` ranks). unique_id: the bytes of rccl_unique_id() from one rank."""
+        buf = C.create_string_buffer(bytes(unique_id), RCCL_ID_BYTES)
+        self._comm_keepalive = None
+        self._native_rank = (rank, size)
+        self._check(_lib.glf_ctx_set_comm_rccl(self._ctx, C.c_int(rank), C.c_int(size), buf, C.c_size_t(RCCL_ID_BYTES),
+                                               C.c_int(1 if force else 0)), "set_comm_rccl")
+
     def set_comm_torch(self, group=None, shard_eigensolve=True, force=False):
         """Plug torch.distributed all-reduces into glf_comm: RCCL on the device buffers in place
         (backend "nccl"), or staged through host memory for a gloo group (CPU rehearsal of the
@@ -481,15 +557,21 @@ class Context:
             ld = 32
             while ld < min(m_req, 256):
                 ld *= 2
-            rows = shard_rows(h, self._comm_keepalive.rank, self._comm_keepalive.size) if self._comm_keepalive else (0, h)
+            if self._comm_keepalive:
+                rows = shard_rows(h, self._comm_keepalive.rank, self._comm_keepalive.size)
+            elif getattr(self, "_native_rank", None):
+                rows = shard_rows(h, *self._native_rank)
+            else:
+                rows = (0, h)
             npix = (rows[1] - rows[0]) * w
             with torch.cuda.stream(self.stream):
                 phi_A = torch.zeros(((p_max + 63) // 64 * 64, ld), dtype=torch.float32, device=self.device)
                 phi = torch.zeros((npix, ld), dtype=torch.float32, device=self.device)
+                corr = torch.zeros(npix, dtype=torch.float32, device=self.device)
             c_host, deg_host = np.zeros(ld, dtype=np.float64), np.zeros(p_max, dtype=np.float64)
             cap = Capture(C.sizeof(Capture), 0, phi_A.data_ptr(), phi_A.numel(), phi.data_ptr(), phi.numel(),
-                          c_host.ctypes.data, deg_host.ctypes.data)
-            keep = (phi_A, phi, c_host, deg_host)
+                          c_host.ctypes.data, deg_host.ctypes.data, corr.data_ptr(), corr.numel())
+            keep = (phi_A, phi, c_host, deg_host, corr)
         rc = _lib.glf_image_processing_capture(self._ctx, C.byref(opt), C.c_void_p(d_img.data_ptr()), C.c_int(w), C.c_int(h),
                                                C.c_void_p(out.data_ptr()), C.c_void_p(zf.data_ptr()) if want_float else None,
                                                lam.ctypes.data_as(C.c_void_p), C.byref(st), C.byref(cap) if cap else None)
@@ -510,7 +592,7 @@ class Context:
         if capture:
             assert cap.ld == keep[0].shape[1], (cap.ld, keep[0].shape)
             info["capture"] = dict(phi_A=keep[0][:st.p], phi=keep[1], c=keep[2][:st.m].copy(), degree=keep[3][:st.p].copy(),
-                                   ld=int(cap.ld))
+                                   corr=keep[4], ld=int(cap.ld))
         return out, zf, info
 
 

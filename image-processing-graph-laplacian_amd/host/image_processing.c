@@ -6,8 +6,13 @@
  *
  *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
- *                    [-dump_eigvecs]
+ *                    [-dump_eigvecs] [-ngpu N [-ngpu_backend rccl|loopback]] [-filter_pow K]
  * -no_approx runs the full-matrix mode (hpc/image_processing.c:155-181); -use_slepc is accepted and refused.
+ * -ngpu N is the reference's `mpirun -n N` (hpc/image_processing.c:30-38, 45-76): ONE process, N GPUs, one context and
+ * one host thread per device, pixel rows sharded, RCCL collectives over xGMI issued by the library (glf_multi_*).
+ * -ngpu_backend loopback runs the N ranks on one device with host-staged collectives (how the sharding is tested on a
+ * one-GPU box). -filter_pow K: f(Pi) = Pi^K (the reference's MatPow(eigvals, 6) drops its result, hpc/utils.c:721, so the
+ * default is K = 1; survey quirk Q3).
  *
  * The approximate path runs the tail the reference left commented out
  * (hpc/image_processing.c:240-275) as its specification (survey quirk Q1).
@@ -209,21 +214,83 @@ out:
     return rows;
 }
 
+static void fill_options(glf_options *opt, unsigned width, unsigned height)
+{
+    glf_options_default(opt);
+    opt->num_samples = GetRequestedSamples(width, height);
+    const char *v = opt_value("-num_eigvals");
+    opt->num_eigvals = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
+    opt->opti_gs = GetOptiGramSchmidt();
+    opt->epsilon = GetInverseIterationEpsilon();
+    opt->h_loc = stage_h_loc;
+    opt->h_val = stage_h_val;
+    opt->gain = stage_gain;
+    if ((v = opt_value("-filter_pow")) && atoi(v) > 0) opt->filter_pow = atoi(v);
+}
+
+static void print_stage_times(const glf_stats *st, double epsilon)
+{
+    printf("Sample size: %d\n", st->p);
+    printf("Computing affinity matrices... %fs\n", st->ms_affinity * 1e-3);
+    printf("Computing Laplacian matrices... %fs\n", st->ms_laplacian * 1e-3);
+    printf("Computing %d smallest eigenvalues... (epsilon: %g) %fs\n", st->m, epsilon, st->ms_eigen * 1e-3);
+    printf("Inverse subspace iteration took %d outer iterations\n", st->eig.outer_its);
+    printf("Computing Nystr\xc3\xb6m approximation... %fs\n", st->ms_nystroem * 1e-3);
+    printf("Computing output image... %fs\n", st->ms_filter * 1e-3);
+}
+
+/* mpirun -n N (hpc/image_processing.c:30-76): N GPUs driven by this one process (glf_multi_*): the image is replicated on
+ * every device, pixel rows are sharded, the result rows come back into one host image. */
+static png_bytep *MultiComputation(png_bytep *img_bytes, unsigned width, unsigned height, int ngpu, int backend)
+{
+    glf_multi *world = NULL;
+    int *devices = NULL;
+    if (backend == GLF_MULTI_LOOPBACK) { /* every rank on the device of -device (default 0) */
+        const char *dev = opt_value("-device");
+        devices = (int *)malloc(sizeof(int) * (size_t)ngpu);
+        for (int r = 0; devices && r < ngpu; ++r) devices[r] = dev ? atoi(dev) : 0;
+    }
+    int rc = glf_multi_create(&world, ngpu, devices, backend);
+    free(devices);
+    if (rc != GLF_OK) {
+        fprintf(stderr, "glf_multi_create(%d GPUs, %s): %s\n", ngpu, backend == GLF_MULTI_RCCL ? "rccl" : "loopback", glf_strerror(rc));
+        return NULL;
+    }
+    glf_options opt;
+    fill_options(&opt, width, height);
+    const size_t n = (size_t)width * height;
+    uint8_t *flat = (uint8_t *)malloc(n), *flat_out = (uint8_t *)calloc(n, 1);
+    glf_stats *st = (glf_stats *)calloc((size_t)ngpu, sizeof(glf_stats));
+    png_bytep *rows = NULL;
+    if (!flat || !flat_out || !st) goto out;
+    for (unsigned r = 0; r < height; ++r) memcpy(flat + (size_t)r * width, img_bytes[r], width);
+    rc = glf_multi_image_processing(world, &opt, flat, (int)width, (int)height, flat_out, NULL, NULL, st);
+    if (rc != GLF_OK) {
+        fprintf(stderr, "glf_multi_image_processing: %s (%s)\n", glf_strerror(rc), glf_multi_last_error(world));
+        goto out;
+    }
+    print_stage_times(&st[0], opt.epsilon);
+    for (int r = 0; r < ngpu; ++r) printf("rank %d: pixel rows [%d, %d), %.3f ms on the device\n", r, st[r].row0, st[r].row1, st[r].ms_total);
+    rows = (png_bytep *)malloc(sizeof(png_bytep) * height);
+    for (unsigned r = 0; rows && r < height; ++r) {
+        rows[r] = (png_bytep)malloc(width);
+        memcpy(rows[r], flat_out + (size_t)r * width, width);
+    }
+out:
+    free(flat);
+    free(flat_out);
+    free(st);
+    glf_multi_destroy(world);
+    return rows;
+}
+
 /* Same path through the single fused entry point (no stage materialisation:
  * Phi is written in raster order directly and K_A is never stored). */
 static png_bytep *FusedComputation(png_bytep *img_bytes, unsigned width, unsigned height)
 {
     glf_ctx *ctx = glf_world();
     glf_options opt;
-    glf_options_default(&opt);
-    opt.num_samples = GetRequestedSamples(width, height);
-    const char *v = opt_value("-num_eigvals");
-    opt.num_eigvals = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
-    opt.opti_gs = GetOptiGramSchmidt();
-    opt.epsilon = GetInverseIterationEpsilon();
-    opt.h_loc = stage_h_loc;
-    opt.h_val = stage_h_val;
-    opt.gain = stage_gain;
+    fill_options(&opt, width, height);
     const size_t n = (size_t)width * height;
     void *d_img = NULL, *d_out = NULL;
     uint8_t *flat = (uint8_t *)malloc(n);
@@ -237,13 +304,7 @@ static png_bytep *FusedComputation(png_bytep *img_bytes, unsigned width, unsigne
         fprintf(stderr, "glf_image_processing: %s (%s)\n", glf_strerror(rc), glf_ctx_last_error(ctx));
         goto out;
     }
-    printf("Sample size: %d\n", st.p);
-    printf("Computing affinity matrices... %fs\n", st.ms_affinity * 1e-3);
-    printf("Computing Laplacian matrices... %fs\n", st.ms_laplacian * 1e-3);
-    printf("Computing %d smallest eigenvalues... (epsilon: %g) %fs\n", st.m, opt.epsilon, st.ms_eigen * 1e-3);
-    printf("Inverse subspace iteration took %d outer iterations\n", st.eig.outer_its);
-    printf("Computing Nystr\xc3\xb6m approximation... %fs\n", st.ms_nystroem * 1e-3);
-    printf("Computing output image... %fs\n", st.ms_filter * 1e-3);
+    print_stage_times(&st, opt.epsilon);
     if (glf_memcpy_d2h(ctx, flat, d_out, n) != GLF_OK) goto out;
     rows = (png_bytep *)malloc(sizeof(png_bytep) * height);
     for (unsigned r = 0; rows && r < height; ++r) {
@@ -265,7 +326,14 @@ int main(int argc, char **argv)
     const char *dev = opt_value("-device");
     if (InitProgram(dev ? atoi(dev) : 0) != GLF_OK) return 2; /* :284 */
     const double start_time = wtime();
-    printf("Running with %d processes\n", 1); /* :286 */
+    const char *ng = opt_value("-ngpu"), *nb = opt_value("-ngpu_backend");
+    const int ngpu = ng ? atoi(ng) : 0; /* 0: the single-context paths below */
+    if (ng && ngpu < 1) {
+        fprintf(stderr, "-ngpu needs a positive device count\n");
+        FinalizeProgram();
+        return 1;
+    }
+    printf("Running with %d processes\n", ngpu > 0 ? ngpu : 1); /* :286: here a "process" is a GPU rank of this one process */
     { /* additions: the reference's constants as flags, same defaults */
         const char *v;
         if ((v = opt_value("-h_loc")) && atof(v) > 0.0) stage_h_loc = (float)atof(v);
@@ -286,6 +354,9 @@ int main(int argc, char **argv)
     int status = 0;
     if (opt_has("-no_approx")) { /* :294-297 */
         output_img = EntireComputation(img_bytes, (unsigned)width, (unsigned)height);
+    } else if (ngpu > 0) {
+        output_img = MultiComputation(img_bytes, (unsigned)width, (unsigned)height, ngpu,
+                                      nb && strcmp(nb, "loopback") == 0 ? GLF_MULTI_LOOPBACK : GLF_MULTI_RCCL);
     } else if (opt_has("-fused")) {
         output_img = FusedComputation(img_bytes, (unsigned)width, (unsigned)height);
     } else {

@@ -19,9 +19,9 @@
  *   K_B, L_B     never stored: a GLF_MAT_KERNEL_B descriptor (image + sample table + scale)
  *
  * Threading: one host thread drives one context; contexts are independent.
- * Multi-GPU: one process per GPU; the caller plugs its collectives in through
- * glf_comm (bench.py uses torch.distributed = RCCL). Pixel rows are sharded,
- * see glf_image_processing.
+ * Multi-GPU: pixel rows are sharded over the ranks (see glf_image_processing); a rank is one GPU. The collectives
+ * are RCCL calls issued by the library itself (glf_ctx_set_comm_rccl: one process per GPU; glf_multi_*: one process,
+ * one thread per GPU), or callbacks the caller plugs in through glf_comm.
  */
 #ifndef GLF_H
 #define GLF_H
@@ -85,6 +85,35 @@ typedef struct glf_comm {
     void *user;
 } glf_comm;
 int glf_ctx_set_comm(glf_ctx *ctx, const glf_comm *comm);
+
+/* ---- native collectives: RCCL inside the library ------------------------------------------------------------------
+ * The reference is an MPI program (hpc/image_processing.c:30-38 SlepcInitialize/MPI_Init, :45-76 broadcast of the image;
+ * every Mat is MATMPIDENSE, hpc/affinity.c:138-142). Here a rank is a GPU and the collectives are RCCL calls the library
+ * issues on the context's stream -- no callback into the host language on the data path:
+ *   all-reduce (f64)  degree partial sums (p), Phi^T y (ld), every inner product / norm / Gram block of the eigen-solve
+ *   all-reduce (f32)  X^T A X of the residual (ld x ld)
+ *   all-gather (f32)  the operand block of each L_A application (hpc/inverse_power_it.c:167: PETSc's MPIDENSE MatMult
+ *                     gathers x the same way) and the final eigenvectors
+ * One process per GPU: glf_rccl_unique_id on one rank, distribute the bytes (MPI / torch.distributed / a file), then
+ * glf_ctx_set_comm_rccl on every rank (ncclCommInitRank; collective over all ranks). force != 0 keeps the collectives
+ * in place on a one-rank world (plumbing test on a single GPU). */
+#define GLF_RCCL_ID_BYTES 128
+int glf_rccl_unique_id(void *id_out, size_t bytes);
+int glf_ctx_set_comm_rccl(glf_ctx *ctx, int rank, int size, const void *unique_id, size_t bytes, int force);
+
+/* One PROCESS driving n GPUs -- the reference's `mpirun -n N image_processing` as `image_processing -ngpu N`: one
+ * context and one host thread per device. GLF_MULTI_RCCL: ncclCommInitAll over `devices` (distinct GPUs of one node,
+ * xGMI). GLF_MULTI_LOOPBACK: the same collectives staged through host memory between the rank threads in fixed rank
+ * order; ranks may share a device (devices[i] may repeat), which RCCL refuses -- this is how the N > 1 sharding of the C
+ * path is tested on a one-GPU box. devices == NULL: 0 .. n-1. */
+typedef struct glf_multi glf_multi;
+enum { GLF_MULTI_RCCL = 0, GLF_MULTI_LOOPBACK = 1 };
+int glf_multi_create(glf_multi **w, int n, const int *devices, int backend);
+int glf_multi_destroy(glf_multi *w);
+int glf_multi_size(const glf_multi *w);
+glf_ctx *glf_multi_ctx(glf_multi *w, int rank);
+const char *glf_multi_last_error(const glf_multi *w);
+/* glf_multi_image_processing: declared below, after glf_options / glf_stats. */
 
 /* How the Nystroem contraction L_B^T (phi_A Pi^-1) (hpc/nystroem.c:42) is evaluated:
  *  F32_MFMA   v_mfma_f32_32x32x2_f32, operands exactly f32 (shares the f32 FMA pipe with the
@@ -293,6 +322,9 @@ typedef struct glf_capture {
     size_t phi_floats;     /* capacity of d_phi in floats */
     double *h_c;           /* host [ld]: right = Phi^T y (hpc/display.c:66), summed over all ranks */
     double *h_degree;      /* host [p]: D_A = rowsum [K_A K_B] (hpc/laplacian.c:18-20), summed over all ranks */
+    float *d_corr;         /* device [pixels of this rank]: the correction gain * Phi (f(Pi) Phi^T y) = z - y before it is added to y
+                              (hpc/display.c:64-73); the float z resolves it to ulp(z) ~ 4e-6 grey levels only */
+    size_t corr_floats;    /* capacity of d_corr in floats */
 } glf_capture;
 int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt, const uint8_t *d_img, int width, int height,
                                  uint8_t *d_out, float *d_zf, double *eigvals_out, glf_stats *stats, glf_capture *cap);
@@ -306,6 +338,13 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt, const uin
  * On failure returns the first failing tile's status; the message is in ctxs[0]'s last error. */
 int glf_image_processing_batch(glf_ctx *const *ctxs, int nctx, const glf_options *opt, const uint8_t *d_imgs,
                                int width, int height, int ntiles, uint8_t *d_outs, float *d_zfs, glf_stats *stats);
+
+/* ReadAndBcastImage + ApproximationComputation + the gather of the result (hpc/image_processing.c:45-76, 183-277,
+ * hpc/utils.c:502-527): h_img / h_out are HOST buffers of height*width bytes; every rank receives the whole image, runs
+ * glf_image_processing on its pixel rows and writes them into h_out (h_zf optional float[N]). stats: HOST glf_stats[n]
+ * or NULL; eigvals_out: HOST double[m] or NULL (rank 0's, identical on every rank). */
+int glf_multi_image_processing(glf_multi *w, const glf_options *opt, const uint8_t *h_img, int width, int height,
+                               uint8_t *h_out, float *h_zf, double *eigvals_out, glf_stats *stats);
 
 /* EntireComputation, hpc/image_processing.c:155-181 (-no_approx): z = clamp(y - L y) with the full N x N
  * Laplacian of ComputeEntireAffinityMatrix / ComputeEntireLaplacianMatrix / ComputeResultFromEntireLaplacian

@@ -45,11 +45,14 @@ def filter_rows(y_rows, phi_rows, lam, c, gain=3.0, filter_pow=1):
     return z, out
 
 
-def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, gain=3.0, prm=None):
+def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, gain=3.0, prm=None, corr_gpu=None):
     """img: u8 [H, W]; idx: sample indices; phi_A: [p, m] (GPU eigenvectors, any float dtype); lam, c: [m];
     rows: image rows to check; phi_gpu(r) -> [W, m] array of the GPU's Phi for image row r (raster order, the sample
-    pixels holding their Phi_A rows, hpc/utils.c:149-152); zf_gpu(r) -> [W] float z before clamp; out_gpu(r) -> [W] u8.
-    Returns a dict of error measures over the checked rows (nothing is asserted here)."""
+    pixels holding their Phi_A rows, hpc/utils.c:149-152); zf_gpu(r) -> [W] float z before clamp; out_gpu(r) -> [W] u8;
+    corr_gpu(r) -> [W] the correction z - y as the filter kernel computed it (glf_capture.d_corr), optional.
+    Returns a dict of error measures over the checked rows (nothing is asserted here). The correction is measured twice:
+    from the float z (bounded below by ulp(z) ~ 4e-6 grey levels, which is 1e-3 of the correction at 4096^2 where the
+    filter moves a pixel by ~1e-3 grey levels RMS) and, when captured, from the correction term itself."""
     h, w = img.shape
     p, m = phi_A.shape
     phi_A64 = np.ascontiguousarray(phi_A.T, dtype=np.float64)        # oracle layout: m vectors of length p
@@ -57,7 +60,7 @@ def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, g
     pos = {int(px): i for i, px in enumerate(idx)}
     phi_err_max = phi_ref_max = 0.0
     rel_big = 0.0
-    num_c = den_c = num_z = den_z = 0.0
+    num_c = den_c = num_z = den_z = num_k = 0.0
     u8_equal = u8_within1 = npx = 0
     u8_maxdiff = 0
     mse = 0.0
@@ -80,6 +83,8 @@ def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, g
         den_c += float(np.sum((z_ref - y) ** 2))
         num_z += float(np.sum((z_got - z_ref) ** 2))
         den_z += float(np.sum(z_ref ** 2))
+        if corr_gpu is not None:
+            num_k += float(np.sum((np.asarray(corr_gpu(r), dtype=np.float64) - (z_ref - y)) ** 2))
         o = np.asarray(out_gpu(r)).astype(np.int64)
         d = np.abs(o - out_ref.astype(np.int64))
         u8_equal += int(np.sum(d == 0))
@@ -92,7 +97,9 @@ def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, g
         "rows": [int(r) for r in rows], "pixels": npx,
         "phi_max_abs_err_over_max": phi_err_max / phi_ref_max if phi_ref_max > 0 else 0.0,
         "phi_max_rel_err_big_entries": rel_big,          # entries > 1e-3 max|Phi row|
-        "rel_l2_correction": (num_c / den_c) ** 0.5 if den_c > 0 else 0.0,   # || z_gpu - z_ref || / || z_ref - y ||
+        "rel_l2_correction_from_float_z": (num_c / den_c) ** 0.5 if den_c > 0 else 0.0,   # || z_gpu - z_ref || / || z_ref - y ||
+        "rel_l2_correction": ((num_k / den_c) ** 0.5 if den_c > 0 else 0.0) if corr_gpu is not None else None,
+        "rms_err_z_grey_levels": (num_c / max(1, npx)) ** 0.5,
         "rel_l2_z": (num_z / den_z) ** 0.5 if den_z > 0 else 0.0,
         "rms_correction_grey_levels": (den_c / max(1, npx)) ** 0.5,
         "u8_equal_frac": u8_equal / max(1, npx), "u8_within1_frac": u8_within1 / max(1, npx), "u8_max_diff": u8_maxdiff,

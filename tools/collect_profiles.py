@@ -4,7 +4,7 @@
 
 Writes profiles/TAG_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py), TAG_bench.json /
 TAG_bench_under_rocprof.json (the JSON lines of the two bench runs), TAG_pmc_summary.json (per-kernel
-counter sums of the --pmc passes; one whole-path run each) and updates profiles/r01_pmc_traffic.json, which
+counter sums of the --pmc passes; one whole-path run each) and updates profiles/pmc_traffic.json, which
 bench.py reads for roofline.traffic. FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as
 MI355X_MICROARCH.md (HBM section) prescribes for gfx950.
 """
@@ -60,7 +60,7 @@ if nys:
     k = max(nys, key=lambda k: summary[k]["FETCH_SIZE"])
     fetch = summary[k]["FETCH_SIZE"] / summary[k]["calls"] * 1024.0 * 2.0
     write = summary[k]["WRITE_SIZE"] / summary[k]["calls"] * 1024.0
-    tf = os.path.join(dst, "r01_pmc_traffic.json")
+    tf = os.path.join(dst, "pmc_traffic.json")
     traffic = json.load(open(tf)) if os.path.exists(tf) else {}
     traffic["4096x4096_m64_f16s_gpus1"] = {
         "nystroem_bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write,
@@ -69,7 +69,7 @@ if nys:
                   "doubled per MI355X_MICROARCH.md (gfx950 counts 16-B/lane reads at half)" % tag}
     json.dump(traffic, open(tf, "w"), indent=1)
     print("nystroem traffic per launch: %.2f GB fetch (x2) + %.2f GB write" % (fetch / 1e9, write / 1e9))
-tf = os.path.join(dst, "r01_pmc_traffic.json")
+tf = os.path.join(dst, "pmc_traffic.json")
 traffic = json.load(open(tf)) if os.path.exists(tf) else {}
 entry = traffic.setdefault("4096x4096_m64_f16s_gpus1", {})
 for name, key in (("k_block_matvec_f16s", "matvec"), ("k_grid_rowpass", "grid_rowpass"), ("k_grid_colpass", "grid_colpass")):
