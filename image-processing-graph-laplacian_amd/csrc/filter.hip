@@ -87,12 +87,18 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
 #pragma unroll
         for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (q == 0) {
-            float z = fmaf(gain, s, (float)img[px]); // MatAXPY(z, 3.0, Lapl_y), hpc/display.c:73
-            if (zf) zf[px] = z;
-            if (corr) corr[px - pix0] = gain * s;    // the correction z - y alone (z ~ 100 in f32 resolves it to 4e-6 only)
-            z = z > 255.f ? 255.f : z;               // AboveXSetY(z, 255, 255), :76
-            z = z > 0.f ? z : 0.f;                   // negative -> 0 (survey quirk Q4; also maps NaN to 0)
-            out[px] = (uint8_t)z;                    // (png_byte) cast = truncation, hpc/utils.c:525
+            const int y = (int)img[px];
+            const float c = gain * s;                // the correction 3.0 * Lapl_y, hpc/display.c:64-73
+            if (zf) zf[px] = (float)y + c;           // MatAXPY(z, 3.0, Lapl_y) as a float (resolves c to ulp(z) only)
+            if (corr) corr[px - pix0] = c;
+            // AboveXSetY(z, 255, 255) (:76), negative -> 0 (survey quirk Q4) and the truncating (png_byte) cast
+            // (hpc/utils.c:525) of the reference's fp64 z = y + c, evaluated WITHOUT rounding the sum to f32 first: y is an
+            // integer, so trunc(y + c) = y + floor(c) wherever y + c >= 0. At 4096^2 |c| ~ 1e-3 grey levels: the f32 sum
+            // rounds y - 2e-6 up to y and 4 % of the pixels then miss the reference's y - 1.
+            int zi = y + (int)floorf(fminf(fmaxf(c, -1.0e6f), 1.0e6f));
+            zi = zi > 255 ? 255 : zi;
+            zi = (zi < 0 || !(c == c)) ? 0 : zi;     // (NaN -> 0, as the float clamp did)
+            out[px] = (uint8_t)zi;
         }
     }
 }

@@ -160,13 +160,19 @@ def test_headline_config_sampled_parity(ctx, size):
     assert res["psnr_db"] >= 50.0
     # the whole image: every pixel's correction follows from its Phi row -- z recomputed in fp64 from the captured Phi
     wv = torch.from_numpy(3.0 * lam * c64).to(ctx.device)
-    z_all = y64 + phi[:, :m].double() @ wv
-    corr = z_all - y64
+    corr = torch.empty(N, dtype=torch.float64, device=ctx.device)
+    for i0 in range(0, N, 1 << 20):                                    # (one 16.7M-row gemv is more than hipBLAS launches)
+        corr[i0:i0 + (1 << 20)] = (phi[i0:i0 + (1 << 20), :m].double() * wv).sum(1)
+    z_all = y64 + corr
     rel_all = float(torch.linalg.norm(cap["corr"].double() - corr) / torch.linalg.norm(corr))
+    report["rel_l2_correction_all_pixels_vs_fp64_from_gpu_phi"] = rel_all
     assert rel_all <= 1e-5, rel_all                                   # the filter kernel itself (f32 dot of 64 terms) on every pixel
     assert float(torch.sqrt(torch.mean((zf.reshape(-1).double() - z_all) ** 2))) <= Z_RMS_TOL
-    out_all = torch.clamp(z_all, 0.0, 255.0).to(torch.uint8)
-    assert float((out_all.reshape(size, size) != out).double().mean()) <= 1e-4   # f32 vs f64 rounding at integer boundaries
+    out_all = torch.clamp(torch.floor(z_all), 0.0, 255.0).to(torch.uint8)        # trunc(z) for z >= 0, 0 below (Q4)
+    mism = float((out_all.reshape(size, size) != out).double().mean())
+    report["u8_mismatch_frac_all_pixels"] = mism
+    _record("large_parity_%d.json" % size, report)
+    assert mism <= 1e-4, mism               # only where the f32 / f64 corrections straddle an integer
 
 
 HDR_KERNELS = [
