@@ -1046,14 +1046,16 @@ constexpr double GSF_COND_FLOOR = 1e-10; // q_k / G_kk below this: fall back to 
 
 // Gpart[chunk][a][b] = sum_{i in chunk} X[i][a] X[i][b] for the tiles on and above the diagonal; 16 x 16 threads, each an
 // E x E sub-block of a TILE x TILE tile.
+// Y (optional): the second operand of G = X^T Y (the cross-panel blocks of more than 256 vectors); then every tile is computed.
 template <int TILE>
 __global__ __launch_bounds__(256) void k_gsf_gram(const float *__restrict__ X, unsigned n, unsigned ld,
-                                                   double *__restrict__ Gpart)
+                                                   double *__restrict__ Gpart, const float *__restrict__ Y = nullptr)
 {
     constexpr int E = TILE / 16;
     const int mb = ld / TILE;
     const int ta = blockIdx.y / mb, tb = blockIdx.y % mb;
-    if (tb < ta) return;
+    if (!Y && tb < ta) return;
+    const float *Yp = Y ? Y : X;
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
     double acc[E][E];
 #pragma unroll
@@ -1064,12 +1066,12 @@ __global__ __launch_bounds__(256) void k_gsf_gram(const float *__restrict__ X, u
     const int ca = ta * TILE + E * ty, cb = tb * TILE + E * tx;
 #pragma unroll 4
     for (unsigned i = r0; i < r1; ++i) {
-        const float *row = X + (size_t)i * ld;
+        const float *row = X + (size_t)i * ld, *rowb = Yp + (size_t)i * ld;
         float a[E], b[E];
 #pragma unroll
         for (int u = 0; u < E; ++u) {
             a[u] = row[ca + u];
-            b[u] = row[cb + u];
+            b[u] = rowb[cb + u];
         }
 #pragma unroll
         for (int u = 0; u < E; ++u)
@@ -1086,13 +1088,13 @@ __global__ __launch_bounds__(256) void k_gsf_gram(const float *__restrict__ X, u
 // G = sum over chunks (fixed order: four interleaved partial sums per entry, combined through LDS), mirrored into the
 // tiles below the diagonal; 64 entries per workgroup
 __global__ __launch_bounds__(256) void k_gsf_sum(const double *__restrict__ Gpart, int nchunks, unsigned ld, int tile,
-                                                  double *__restrict__ G)
+                                                  double *__restrict__ G, int full = 0)
 {
     __shared__ double sh[256];
     const unsigned e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
     const unsigned a = e / ld, b = e % ld;
-    const bool live = e < ld * ld && b / tile >= a / tile;
+    const bool live = e < ld * ld && (full || b / tile >= a / tile);
     double s = 0.0;
     if (live) { // eight chunks' loads in flight at a time, added in the same order
         int c = part;
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_gsf_sum(const double *__restrict__ Gpar
     if (threadIdx.x < 64 && live) {
         const double tot = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
         G[e] = tot;
-        if (b / tile > a / tile) G[(size_t)b * ld + a] = tot;
+        if (!full && b / tile > a / tile) G[(size_t)b * ld + a] = tot;
     }
 }
 
@@ -1297,6 +1299,42 @@ __global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsign
             const unsigned i = r0 + rl + q * nrl;
             if (i < n) X[(size_t)i * ld + col] = (float)acc[q];
         }
+}
+
+// Y[i][c] -= sum_a X[i][a] C[a][c] (f64 accumulation), a < ma: the projection of one block of vectors onto an earlier,
+// already orthonormal block (the cross-panel terms of classical Gram-Schmidt for more than 256 vectors, and X (X^T A X) of the
+// residual). Same tiling as k_gsf_apply.
+__global__ __launch_bounds__(256) void k_gsf_sub(float *__restrict__ Y, const float *__restrict__ X, unsigned n, unsigned ld, unsigned ma,
+                                                  const double *__restrict__ Cm)
+{
+    __shared__ float xs[GSF_APPLY_TILE];
+    __shared__ double ts[4096];
+    const unsigned rows = GSF_APPLY_TILE / ld, jb = min(4096u / ld, ld);
+    const unsigned r0 = blockIdx.x * rows;
+    const unsigned col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    for (unsigned e = threadIdx.x; e < rows * ld; e += 256) {
+        const unsigned i = r0 + e / ld;
+        xs[e] = i < n ? X[(size_t)i * ld + e % ld] : 0.f;
+    }
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (unsigned j0 = 0; j0 < ma; j0 += jb) {
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < jb * ld; e += 256) ts[e] = Cm[(size_t)j0 * ld + e];
+        __syncthreads();
+        const unsigned jn = min(jb, ma - j0);
+        for (unsigned j = 0; j < jn; ++j) {
+            const double tv = ts[j * ld + col];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fma((double)xs[(rl + q * nrl) * ld + j0 + j], tv, acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned i = r0 + rl + q * nrl;
+        if (i < n) Y[(size_t)i * ld + col] = (float)((double)Y[(size_t)i * ld + col] - acc[q]);
+    }
 }
 
 struct GsFusedWork {
@@ -1750,6 +1788,222 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         stats->matvec_bytes = ctx->mv_bytes - mv_bytes0;
     }
     return rc;
+}
+
+// =====================================================================================
+// More than 256 eigenpairs (the reference's default is m = p - 1, hpc/image_processing.c:96-108)
+// =====================================================================================
+// The m vectors are held as ceil(m / 256) PANELS of 256 columns, panel q a [rows][256] block of its own (the last one
+// zero-padded), so that every kernel above runs unchanged on one panel. Columns are independent in the inner solves, the
+// operator applications and the final normalisation; the two places where vectors meet are
+//   * classical Gram-Schmidt: for panel q the coefficients <v_k, u_j> against every EARLIER panel come from the original
+//     v_k (C_jq = X_j^T V_q for all j < q first, then V_q -= sum_j X_j C_jq -- exactly the classical sweep's terms,
+//     hpc/gram_schmidt.c:47-57, as small f64 GEMMs), then the panel is orthonormalised within itself (Gram-matrix form);
+//   * the residual || A X - X (X^T A X) ||_F: R_j = A X_j - sum_i X_i (X_i^T A X_j), panel pair by panel pair.
+// This path is about coverage, not speed (O(p m^2) f64 work on the vector pipe); it is single-rank (or replicated).
+constexpr unsigned PANEL = 256;
+
+struct PanelWork {
+    DevBuf<double> Gpart, C;   // Gram chunks; the coefficient blocks C_jq of one panel q (npan x 256 x 256)
+    DevBuf<float> R;           // one residual panel
+    DevBuf<double> partial, sums;
+    int nchunks = 0;
+    int init(glf_ctx *ctx, unsigned p, unsigned npan)
+    {
+        nchunks = (int)ceil_div(p, GSF_ROWS);
+        GLF_TRY(Gpart.alloc(ctx, (size_t)nchunks * PANEL * PANEL));
+        GLF_TRY(C.alloc(ctx, (size_t)npan * PANEL * PANEL));
+        GLF_TRY(R.alloc(ctx, (size_t)round_up(p, VEC_PAD) * PANEL));
+        GLF_TRY(partial.alloc(ctx, (size_t)ceil_div(p, RED_ROWS) * PANEL));
+        GLF_TRY(sums.alloc(ctx, PANEL));
+        return GLF_OK;
+    }
+};
+
+// C = X^T Y in f64 ([256][256], all entries), X and Y two panels of n rows
+static int panel_gram(glf_ctx *ctx, PanelWork &w, const float *X, const float *Y, unsigned n, double *C)
+{
+    const int mb = PANEL / 64;
+    hipLaunchKernelGGL((k_gsf_gram<64>), dim3(w.nchunks, mb * mb), dim3(256), 0, ctx->stream, X, n, PANEL, w.Gpart.p, Y);
+    hipLaunchKernelGGL(k_gsf_sum, dim3((PANEL * PANEL + 63) / 64), dim3(256), 0, ctx->stream, w.Gpart.p, w.nchunks, PANEL, 64, C, 1);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+static inline unsigned panel_cols(unsigned m, unsigned q) { return std::min(PANEL, m - q * PANEL); }
+
+// OrthonormaliseVecs over all panels; norms: device double [npan * 256]
+static int panels_orthonormalise(glf_ctx *ctx, GsWork &gs, PanelWork &w, float *X, size_t pstride, unsigned p, unsigned m,
+                                 double *d_norms)
+{
+    const unsigned npan = (unsigned)ceil_div(m, PANEL);
+    hipStream_t st = ctx->stream;
+    for (unsigned q = 0; q < npan; ++q) {
+        float *Vq = X + q * pstride;
+        for (unsigned j = 0; j < q; ++j) // <v_k, u_j> from the ORIGINAL v_k (classical Gram-Schmidt), all earlier panels first
+            GLF_TRY(panel_gram(ctx, w, X + j * pstride, Vq, p, w.C.p + (size_t)j * PANEL * PANEL));
+        for (unsigned j = 0; j < q; ++j)
+            hipLaunchKernelGGL(k_gsf_sub, dim3((unsigned)ceil_div(p, GSF_APPLY_TILE / PANEL)), dim3(256), 0, st, Vq, X + j * pstride, p, PANEL,
+                               PANEL, w.C.p + (size_t)j * PANEL * PANEL);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_TRY(orthonormalise_dev(ctx, gs, Vq, p, panel_cols(m, q), PANEL));
+        GLF_HIP(ctx, hipMemcpyAsync(d_norms + (size_t)q * PANEL, gs.norms.p, sizeof(double) * PANEL, hipMemcpyDeviceToDevice, st));
+    }
+    return GLF_OK;
+}
+
+// || A X - X (X^T A X) ||_F over all panels (AX: npan panels of scratch)
+static int panels_residual(glf_ctx *ctx, PanelWork &w, const float *A, int64_t lda, unsigned p, float *X, float *AX, size_t pstride,
+                           unsigned m, const MatShard *shard, double *h_out)
+{
+    const unsigned npan = (unsigned)ceil_div(m, PANEL);
+    hipStream_t st = ctx->stream;
+    const int nblk = (int)ceil_div(p, RED_ROWS);
+    for (unsigned j = 0; j < npan; ++j) GLF_TRY(block_matvec(ctx, A, lda, p, X + j * pstride, AX + j * pstride, PANEL, shard));
+    double ss = 0.0;
+    std::vector<double> h(PANEL);
+    for (unsigned j = 0; j < npan; ++j) {
+        GLF_HIP(ctx, hipMemcpyAsync(w.R.p, AX + j * pstride, sizeof(float) * (size_t)p * PANEL, hipMemcpyDeviceToDevice, st));
+        for (unsigned i = 0; i < npan; ++i) {
+            GLF_TRY(panel_gram(ctx, w, X + i * pstride, AX + j * pstride, p, w.C.p));
+            hipLaunchKernelGGL(k_gsf_sub, dim3((unsigned)ceil_div(p, GSF_APPLY_TILE / PANEL)), dim3(256), 0, st, w.R.p, X + i * pstride, p,
+                               PANEL, panel_cols(m, i), w.C.p);
+        }
+        hipLaunchKernelGGL(k_col_sumsq, dim3(nblk), dim3(256), 0, st, w.R.p, p, PANEL, w.partial.p);
+        hipLaunchKernelGGL(k_sum_partials_nv<1>, dim3(1), dim3(256), 0, st, w.partial.p, nblk, PANEL, w.sums.p);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_HIP(ctx, hipMemcpyAsync(h.data(), w.sums.p, sizeof(double) * PANEL, hipMemcpyDeviceToHost, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+        for (unsigned c = 0; c < panel_cols(m, j); ++c) ss += h[c];
+    }
+    *h_out = std::sqrt(ss);
+    return GLF_OK;
+}
+
+// InversePowerIteration for m > 256. d_eigvecs: npan panels of [round_up(p, 64)][256] (panel-major); X0 = the seeded start
+// block (hpc/inverse_power_it.c:12-47), host double [m][p] or nullptr for glf_random_vectors(seed).
+int inverse_power_iteration_panels(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, const double *h_X0,
+                                   unsigned long long seed, int opti_gs, double epsilon, double inner_rtol, int max_outer,
+                                   float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats, const MatShard *shard,
+                                   const float *d_dinv)
+{
+    if (m <= PANEL || m > p) return set_error(ctx, GLF_ERR_INVALID, "inverse_power_iteration_panels: m=%u p=%u", m, p);
+    if (shard && shard->rows_per_rank) return set_error(ctx, GLF_ERR_UNSUPPORTED, "more than 256 eigenpairs: the eigen-solve is not row-sharded");
+    if (opti_gs < 1) opti_gs = 1;
+    const unsigned npan = (unsigned)ceil_div(m, PANEL), p32 = (unsigned)round_up(p, VEC_PAD);
+    const size_t pstride = (size_t)p32 * PANEL, total = pstride * npan;
+    hipStream_t st = ctx->stream;
+    DevBuf<float> X, Xb, AX;
+    DevBuf<double> norms;
+    GLF_TRY(X.alloc(ctx, total));
+    GLF_TRY(Xb.alloc(ctx, total));
+    GLF_TRY(AX.alloc(ctx, total));
+    GLF_TRY(norms.alloc(ctx, (size_t)npan * PANEL));
+    {
+        std::vector<double> own;
+        if (!h_X0) {
+            own.resize((size_t)m * p);
+            glf_random_vectors(own.data(), p, m, seed);
+            h_X0 = own.data();
+        }
+        std::vector<float> h(total, 0.f);
+        for (unsigned j = 0; j < m; ++j)
+            for (unsigned i = 0; i < p; ++i) h[(j / PANEL) * pstride + (size_t)i * PANEL + j % PANEL] = (float)h_X0[(size_t)j * p + i];
+        GLF_HIP(ctx, hipMemcpyAsync(X.p, h.data(), sizeof(float) * total, hipMemcpyHostToDevice, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+    }
+    GLF_HIP(ctx, hipMemsetAsync(AX.p, 0, sizeof(float) * total, st));
+    GsWork gs;
+    GLF_TRY(gs.init(ctx, p, PANEL));
+    CgWork cg;
+    GLF_TRY(cg.init(ctx, p, PANEL, shard));
+    PanelWork pw;
+    GLF_TRY(pw.init(ctx, p, npan));
+    if (d_dinv) GLF_HIP(ctx, hipMemcpyAsync(cg.dinv.p, d_dinv, sizeof(float) * p, hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_TRY(mv_collect(ctx));
+    const int mv_count0 = ctx->mv_count;
+    const double mv_ms0 = ctx->mv_ms, mv_bytes0 = ctx->mv_bytes;
+
+    GLF_TRY(panels_orthonormalise(ctx, gs, pw, X.p, pstride, p, m, norms.p)); // :95
+    GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * total, hipMemcpyDeviceToDevice, st));
+    double r_norm = 0.0;
+    GLF_TRY(panels_residual(ctx, pw, A, lda, p, X.p, AX.p, pstride, m, shard, &r_norm)); // :159
+    const bool verbose = std::getenv("GLF_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[glf] %u panels; initial residual %.9g\n", npan, r_norm);
+    int it = 0, inner_total = 0, rc = GLF_OK;
+    while (r_norm > epsilon) { // :161
+        if (it >= max_outer) {
+            rc = set_error(ctx, GLF_ERR_NOCONV, "inverse iteration: residual %g > %g after %d outer iterations", r_norm, epsilon, it);
+            break;
+        }
+        ++it;
+        int inner_max = 0;
+        for (unsigned q = 0; q < npan; ++q) { // :165-168: the solves are independent column by column
+            int inner = 0;
+            GLF_TRY(block_pcg_work(ctx, cg, A, lda, p, X.p + q * pstride, panel_cols(m, q), PANEL, inner_rtol, 10 * (int)p + 100, &inner));
+            inner_max = std::max(inner_max, inner);
+        }
+        inner_total += inner_max; // block-Krylov steps of the slowest panel (what the single-panel count means)
+        GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * total, hipMemcpyDeviceToDevice, st)); // CopyVecs :171
+        if (it % opti_gs == 0) GLF_TRY(panels_orthonormalise(ctx, gs, pw, X.p, pstride, p, m, norms.p)); // :174-177
+        GLF_TRY(panels_residual(ctx, pw, A, lda, p, X.p, AX.p, pstride, m, shard, &r_norm)); // :180
+        if (verbose) fprintf(stderr, "[glf] outer iteration %d: %d block-CG steps, residual %.9g\n", it, inner_max, r_norm);
+    }
+    if (opti_gs != 1 && (it % opti_gs) != 0) GLF_TRY(panels_orthonormalise(ctx, gs, pw, X.p, pstride, p, m, norms.p)); // :183-186
+    if (h_eigvals) { // eigenvalues = 1 / norms, :204
+        std::vector<double> nr((size_t)npan * PANEL);
+        GLF_HIP(ctx, hipMemcpyAsync(nr.data(), norms.p, sizeof(double) * nr.size(), hipMemcpyDeviceToHost, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+        for (unsigned j = 0; j < m; ++j) h_eigvals[j] = 1.0 / nr[j];
+    }
+    if (d_eigvecs) { // NormaliseVecs(X_k_before_orth), :230
+        for (unsigned q = 0; q < npan; ++q)
+            GLF_TRY(normalise_dev(ctx, Xb.p + q * pstride, p, panel_cols(m, q), PANEL, gs.partial.p, gs.norms.p));
+        GLF_HIP(ctx, hipMemcpyAsync(d_eigvecs, Xb.p, sizeof(float) * total, hipMemcpyDeviceToDevice, st));
+    }
+    GLF_HIP(ctx, hipStreamSynchronize(st));
+    GLF_TRY(mv_collect(ctx));
+    if (stats) {
+        stats->outer_its = it;
+        stats->inner_its_total = inner_total;
+        stats->residual = r_norm;
+        stats->matvecs = ctx->mv_count - mv_count0;
+        stats->matvec_ms = (float)(ctx->mv_ms - mv_ms0);
+        stats->matvec_bytes = ctx->mv_bytes - mv_bytes0;
+    }
+    return rc;
+}
+
+// OrthonormaliseVecs / NormaliseVecs on a panel-major block of more than 256 vectors (stage API)
+int orthonormalise_panels(glf_ctx *ctx, float *X, unsigned n, unsigned m, double *h_norms, bool normalise_only)
+{
+    const unsigned npan = (unsigned)ceil_div(m, PANEL), n32 = (unsigned)round_up(n, VEC_PAD);
+    const size_t pstride = (size_t)n32 * PANEL;
+    GsWork gs;
+    GLF_TRY(gs.init(ctx, n, PANEL));
+    DevBuf<double> norms;
+    GLF_TRY(norms.alloc(ctx, (size_t)npan * PANEL));
+    if (normalise_only) {
+        for (unsigned q = 0; q < npan; ++q) {
+            GLF_TRY(normalise_dev(ctx, X + q * pstride, n, panel_cols(m, q), PANEL, gs.partial.p, gs.norms.p));
+            GLF_HIP(ctx, hipMemcpyAsync(norms.p + (size_t)q * PANEL, gs.norms.p, sizeof(double) * PANEL, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    } else {
+        PanelWork pw;
+        GLF_TRY(pw.init(ctx, n, npan));
+        GLF_TRY(panels_orthonormalise(ctx, gs, pw, X, pstride, n, m, norms.p));
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (h_norms) {
+        std::vector<double> h((size_t)npan * PANEL);
+        GLF_HIP(ctx, hipMemcpyAsync(h.data(), norms.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (unsigned j = 0; j < m; ++j) h_norms[j] = h[j];
+    }
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
 }
 
 } // namespace glf

@@ -71,6 +71,18 @@ int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0
     return GLF_OK;
 }
 
+// AboveXSetY(z, 255, 255) (hpc/display.c:76), negative -> 0 (survey quirk Q4) and the truncating (png_byte) cast
+// (hpc/utils.c:525) of the reference's fp64 z = y + c, evaluated WITHOUT rounding the sum to f32 first: y is an integer, so
+// trunc(y + c) = y + floor(c) wherever y + c >= 0. At 4096^2 |c| ~ 1e-3 grey levels: the f32 sum rounds y - 2e-6 up to y
+// and 4 % of the pixels then miss the reference's y - 1.
+__device__ __forceinline__ uint8_t filter_output(int y, float c)
+{
+    int zi = y + (int)floorf(fminf(fmaxf(c, -1.0e6f), 1.0e6f));
+    zi = zi > 255 ? 255 : zi;
+    zi = (zi < 0 || !(c == c)) ? 0 : zi; // (NaN -> 0)
+    return (uint8_t)zi;
+}
+
 // z[pix] = y + gain * sum_j Phi[pix][j] w[j]; LD/4 lanes per pixel, float4 each.
 template <int LD>
 __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict__ img, const float *__restrict__ phi,
@@ -91,14 +103,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
             const float c = gain * s;                // the correction 3.0 * Lapl_y, hpc/display.c:64-73
             if (zf) zf[px] = (float)y + c;           // MatAXPY(z, 3.0, Lapl_y) as a float (resolves c to ulp(z) only)
             if (corr) corr[px - pix0] = c;
-            // AboveXSetY(z, 255, 255) (:76), negative -> 0 (survey quirk Q4) and the truncating (png_byte) cast
-            // (hpc/utils.c:525) of the reference's fp64 z = y + c, evaluated WITHOUT rounding the sum to f32 first: y is an
-            // integer, so trunc(y + c) = y + floor(c) wherever y + c >= 0. At 4096^2 |c| ~ 1e-3 grey levels: the f32 sum
-            // rounds y - 2e-6 up to y and 4 % of the pixels then miss the reference's y - 1.
-            int zi = y + (int)floorf(fminf(fmaxf(c, -1.0e6f), 1.0e6f));
-            zi = zi > 255 ? 255 : zi;
-            zi = (zi < 0 || !(c == c)) ? 0 : zi;     // (NaN -> 0, as the float clamp did)
-            out[px] = (uint8_t)zi;
+            out[px] = filter_output(y, c);
         }
     }
 }
@@ -118,6 +123,54 @@ int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t
     case 128: hipLaunchKernelGGL(k_apply_filter<128>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
     case 256: hipLaunchKernelGGL(k_apply_filter<256>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
     }
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+// ---- the same filter for more than 256 eigenpairs: one 256-column panel of Phi at a time ------------------------------
+__global__ __launch_bounds__(256) void k_filter_accum(const float *__restrict__ phi, int64_t pix0, int64_t pix1,
+                                                       const float *__restrict__ w, float *__restrict__ acc, int first)
+{
+    constexpr int LD = 256, LPP = LD / 4, PPB = 256 / LPP;
+    const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const float4 wq = reinterpret_cast<const float4 *>(w)[q];
+    for (int64_t px = pix0 + (int64_t)blockIdx.x * PPB + pl; px < pix1; px += (int64_t)gridDim.x * PPB) {
+        const float4 f = reinterpret_cast<const float4 *>(phi + (size_t)(px - pix0) * LD)[q];
+        float s = f.x * wq.x + f.y * wq.y + f.z * wq.z + f.w * wq.w;
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (q == 0) acc[px - pix0] = first ? s : acc[px - pix0] + s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_filter_finish(const uint8_t *__restrict__ img, const float *__restrict__ acc, int64_t pix0,
+                                                        int64_t pix1, float gain, uint8_t *__restrict__ out, float *__restrict__ zf)
+{
+    const int64_t px = pix0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (px >= pix1) return;
+    const int y = (int)img[px];
+    const float c = gain * acc[px - pix0];
+    if (zf) zf[px] = (float)y + c;
+    out[px] = filter_output(y, c);
+}
+
+// d_phi: this panel's rows for the pixels [pix0, pix1), [pix1 - pix0][256]
+int filter_accumulate(glf_ctx *ctx, const float *d_phi, int64_t pix0, int64_t pix1, unsigned ld, const float *d_w, float *d_acc, bool first)
+{
+    if (ld != PANEL_COLS || pix0 > pix1) return set_error(ctx, GLF_ERR_INVALID, "filter_accumulate: ld=%u", ld);
+    if (pix0 == pix1) return GLF_OK;
+    int64_t nblk = ceil_div(pix1 - pix0, 4);
+    if (nblk > 8192) nblk = 8192;
+    hipLaunchKernelGGL(k_filter_accum, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, d_phi, pix0, pix1, d_w, d_acc, first ? 1 : 0);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
+}
+
+int filter_finish(glf_ctx *ctx, const uint8_t *d_img, const float *d_acc, int64_t pix0, int64_t pix1, float gain, uint8_t *d_out, float *d_zf)
+{
+    if (pix0 >= pix1) return GLF_OK;
+    hipLaunchKernelGGL(k_filter_finish, dim3((unsigned)ceil_div(pix1 - pix0, 256)), dim3(256), 0, ctx->stream, d_img, d_acc, pix0, pix1, gain,
+                       d_out, d_zf);
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
 }

@@ -110,6 +110,11 @@ inline int64_t ceil_div(int64_t x, int64_t q) { return (x + q - 1) / q; }
 // (the column-reduction kernels map 256 threads onto 256/ld row lanes x ld columns).
 inline unsigned ld_for(unsigned m) { unsigned ld = 32; while (ld < m) ld <<= 1; return ld; }
 inline bool valid_ld(unsigned ld) { return ld == 32 || ld == 64 || ld == 128 || ld == 256; }
+// More than 256 vectors: row-major matrices of the C-ABI carry ld = m rounded up to a multiple of 256; internally the
+// vectors are processed as panels of 256 columns, each a contiguous [rows][256] block (eigen.hip, "panels").
+constexpr unsigned PANEL_COLS = 256;
+inline bool wide_ld(unsigned ld) { return ld > PANEL_COLS && ld % PANEL_COLS == 0; }
+inline unsigned ld_total_for(unsigned m) { return m <= PANEL_COLS ? ld_for(m) : (unsigned)round_up(m, PANEL_COLS); }
 
 constexpr size_t POOL_GUARD_BYTES = 4096;            // debug pool: canary bytes after every block
 constexpr int POOL_CANARY = 0xA5;
@@ -299,6 +304,13 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
                             const MatShard *shard = nullptr, const float *d_dinv = nullptr,
                             const float *d_X0_block = nullptr);
 
+// m > 256 (the reference default m = p - 1): panel-major blocks, see eigen.hip
+int inverse_power_iteration_panels(glf_ctx *ctx, const float *A, int64_t lda, unsigned p, unsigned m, const double *h_X0,
+                                   unsigned long long seed, int opti_gs, double epsilon, double inner_rtol, int max_outer,
+                                   float *d_eigvecs, double *h_eigvals, glf_eig_stats *stats, const MatShard *shard,
+                                   const float *d_dinv);
+int orthonormalise_panels(glf_ctx *ctx, float *X, unsigned n, unsigned m, double *h_norms, bool normalise_only);
+
 // Nystroem contraction (nystroem.hip): Phi[pix][j] = sum_i scale*K(sample i, pix) * Psi[i][j]
 // for pixels [pix0, pix1). raster != 0: row = pix; else sample-first (rows of sample pixels skipped).
 // cpart (optional): m doubles, += sum over NON-sample pixels of Phi[pix][j] * y[pix].
@@ -321,5 +333,10 @@ int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0
             unsigned ld, double *d_c);
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1,
                  unsigned m, unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf, float *d_corr = nullptr);
+// the same filter panel by panel (m > 256): acc[px - pix0] (+)= sum_j Phi[px][j] w[j], then z = y + gain * acc
+int filter_accumulate(glf_ctx *ctx, const float *d_phi, int64_t pix0, int64_t pix1, unsigned ld, const float *d_w, float *d_acc,
+                      bool first);
+int filter_finish(glf_ctx *ctx, const uint8_t *d_img, const float *d_acc, int64_t pix0, int64_t pix1, float gain, uint8_t *d_out,
+                  float *d_zf);
 
 } // namespace glf

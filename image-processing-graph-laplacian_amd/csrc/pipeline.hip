@@ -47,6 +47,20 @@ __global__ void k_diag_inverse(const float *__restrict__ x, unsigned n, float *_
     if (i < n) y[i] = 1.0f / x[i]; // InverseDiagMat, hpc/utils.c:578-579
 }
 
+// 256-column panel q of a row-major [rows][ld_total] matrix <-> a contiguous [rows][256] block (m > 256, see eigen.hip "panels")
+static int pack_panel(glf_ctx *ctx, const float *rm, int64_t ld_total, int64_t rows, unsigned q, float *panel)
+{
+    GLF_HIP(ctx, hipMemcpy2DAsync(panel, sizeof(float) * PANEL_COLS, rm + (size_t)q * PANEL_COLS, sizeof(float) * (size_t)ld_total,
+                                  sizeof(float) * PANEL_COLS, (size_t)rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return GLF_OK;
+}
+static int unpack_panel(glf_ctx *ctx, const float *panel, int64_t ld_total, int64_t rows, unsigned q, float *rm)
+{
+    GLF_HIP(ctx, hipMemcpy2DAsync(rm + (size_t)q * PANEL_COLS, sizeof(float) * (size_t)ld_total, panel, sizeof(float) * PANEL_COLS,
+                                  sizeof(float) * PANEL_COLS, (size_t)rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return GLF_OK;
+}
+
 static int sum_host(glf_ctx *ctx, const double *d_v, unsigned n, double *out)
 {
     std::vector<double> h(n);
@@ -55,6 +69,22 @@ static int sum_host(glf_ctx *ctx, const double *d_v, unsigned n, double *out)
     double s = 0.0;
     for (unsigned i = 0; i < n; ++i) s += h[i];
     *out = s;
+    return GLF_OK;
+}
+
+// OrthonormaliseVecs / NormaliseVecs for more than 256 vectors: row-major in, panels inside, row-major out
+static int orthonormalise_wide(glf_ctx *ctx, glf_mat *X, double *norms, bool normalise_only)
+{
+    const unsigned n = (unsigned)X->rows, m = (unsigned)X->cols, ld = (unsigned)X->ld;
+    if (!wide_ld(ld) || m > ld) return set_error(ctx, GLF_ERR_INVALID, "more than 256 vectors need ld = a multiple of 256 (ld = %u)", ld);
+    const unsigned npan = (unsigned)ceil_div(m, PANEL_COLS), n32 = (unsigned)round_up(n, VEC_PAD);
+    DevBuf<float> panels;
+    GLF_TRY(panels.alloc(ctx, (size_t)npan * n32 * PANEL_COLS));
+    GLF_HIP(ctx, hipMemsetAsync(panels.p, 0, sizeof(float) * (size_t)npan * n32 * PANEL_COLS, ctx->stream));
+    for (unsigned q = 0; q < npan; ++q) GLF_TRY(pack_panel(ctx, X->data, ld, n, q, panels.p + (size_t)q * n32 * PANEL_COLS));
+    GLF_TRY(orthonormalise_panels(ctx, panels.p, n, m, norms, normalise_only));
+    for (unsigned q = 0; q < npan; ++q) GLF_TRY(unpack_panel(ctx, panels.p + (size_t)q * n32 * PANEL_COLS, ld, n, q, X->data));
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;
 }
 
@@ -198,9 +228,34 @@ int glf_InversePowerIteration(glf_ctx *ctx, const glf_mat *A, unsigned m, glf_ma
     GLF_ENTER(ctx);
     const unsigned p = (unsigned)A->rows;
     if (m == 0 || m >= p) return set_error(ctx, GLF_ERR_INVALID, "need 0 < m < p (m=%u p=%u)", m, p);
-    if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "m = %u > 256 eigenpairs not supported", m);
-    const unsigned ld = ld_for(m);
+    const unsigned ld = ld_total_for(m);
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
+    if (m > PANEL_COLS) { // panels of 256 vectors (the reference default m = p - 1, hpc/image_processing.c:96-108)
+        const unsigned npan = ld / PANEL_COLS;
+        glf_mat wide;
+        GLF_TRY(glf_mat_create_dense(ctx, &wide, p32, m, ld));
+        wide.rows = p;
+        DevBuf<float> panels;
+        GLF_TRY(panels.alloc(ctx, (size_t)npan * p32 * PANEL_COLS));
+        std::vector<double> lamw(m);
+        int rcw = inverse_power_iteration_panels(ctx, A->data, A->ld, p, m, X0, 1, optiGramSchmidt, epsilon, inner_rtol,
+                                                 max_outer > 0 ? max_outer : 100000, panels.p, lamw.data(), stats, nullptr, nullptr);
+        if (rcw != GLF_OK && rcw != GLF_ERR_NOCONV) {
+            glf_mat_destroy(ctx, &wide);
+            return rcw;
+        }
+        for (unsigned q = 0; q < npan; ++q) GLF_TRY(unpack_panel(ctx, panels.p + (size_t)q * p32 * PANEL_COLS, ld, p32, q, wide.data));
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (eigenvalues) {
+            GLF_TRY(glf_mat_create_diag(ctx, eigenvalues, m));
+            std::vector<float> lf(m);
+            for (unsigned j = 0; j < m; ++j) lf[j] = (float)lamw[j];
+            GLF_TRY(glf_memcpy_h2d(ctx, eigenvalues->data, lf.data(), sizeof(float) * m));
+        }
+        if (eigenvectors) *eigenvectors = wide;
+        else glf_mat_destroy(ctx, &wide);
+        return rcw;
+    }
     glf_mat vecs;
     GLF_TRY(glf_mat_create_dense(ctx, &vecs, p32, m, ld));
     vecs.rows = p;
@@ -227,6 +282,7 @@ int glf_OrthonormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms)
 {
     if (!ctx || !X || X->kind != GLF_MAT_DENSE) return GLF_ERR_INVALID;
     GLF_ENTER(ctx);
+    if (X->cols > PANEL_COLS) return orthonormalise_wide(ctx, X, norms, false);
     return orthonormalise(ctx, X->data, (unsigned)X->rows, (unsigned)X->cols, (unsigned)X->ld, norms);
 }
 
@@ -234,6 +290,7 @@ int glf_NormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms)
 {
     if (!ctx || !X || X->kind != GLF_MAT_DENSE) return GLF_ERR_INVALID;
     GLF_ENTER(ctx);
+    if (X->cols > PANEL_COLS) return orthonormalise_wide(ctx, X, norms, true);
     return normalise(ctx, X->data, (unsigned)X->rows, (unsigned)X->cols, (unsigned)X->ld, norms);
 }
 
@@ -255,10 +312,35 @@ int glf_Nystroem(glf_ctx *ctx, const glf_mat *B, const glf_mat *phi_A, const glf
     if (B->kind != GLF_MAT_KERNEL_B || phi_A->kind != GLF_MAT_DENSE || Pi_A_Inv->kind != GLF_MAT_DIAG)
         return set_error(ctx, GLF_ERR_INVALID, "Nystroem: B must be a KERNEL_B descriptor, phi_A dense, Pi_A_Inv diagonal");
     const unsigned p = B->p, m = (unsigned)phi_A->cols, ld = (unsigned)phi_A->ld;
-    if (phi_A->rows != p || Pi_A_Inv->rows != m || !valid_ld(ld))
+    if (phi_A->rows != p || Pi_A_Inv->rows != m || !(valid_ld(ld) || wide_ld(ld)) || m > ld)
         return set_error(ctx, GLF_ERR_INVALID, "Nystroem: shape mismatch (p=%u, phi_A %lld x %u ld %u)", p,
                          (long long)phi_A->rows, m, ld);
     const int64_t N = (int64_t)B->width * B->height;
+    if (wide_ld(ld)) { // more than 256 eigenvectors: one 256-column panel of Phi at a time (columns are independent)
+        const unsigned npan = (unsigned)ceil_div(m, PANEL_COLS), p64 = (unsigned)round_up(p, NYS_PAD);
+        DevBuf<float> pa, psiw, phip;
+        GLF_TRY(pa.alloc(ctx, (size_t)p64 * PANEL_COLS));
+        GLF_TRY(psiw.alloc(ctx, (size_t)p64 * PANEL_COLS));
+        GLF_TRY(phip.alloc(ctx, (size_t)N * PANEL_COLS));
+        GLF_TRY(glf_mat_create_dense(ctx, phi, N, m, ld));
+        phi->row_order = GLF_ROWS_SAMPLE_FIRST;
+        const KernelCoef coefw = make_coef(B->kernel, B->h_loc, B->h_val);
+        for (unsigned q = 0; q < npan; ++q) {
+            const unsigned mq = std::min(PANEL_COLS, m - q * PANEL_COLS);
+            GLF_HIP(ctx, hipMemsetAsync(pa.p, 0, sizeof(float) * (size_t)p64 * PANEL_COLS, ctx->stream));
+            GLF_HIP(ctx, hipMemsetAsync(psiw.p, 0, sizeof(float) * (size_t)p64 * PANEL_COLS, ctx->stream));
+            GLF_TRY(pack_panel(ctx, phi_A->data, ld, p, q, pa.p));
+            hipLaunchKernelGGL(k_make_psi, dim3((unsigned)ceil_div((int64_t)p * PANEL_COLS, 256)), dim3(256), 0, ctx->stream, pa.p,
+                               Pi_A_Inv->data + (size_t)q * PANEL_COLS, p, PANEL_COLS, mq, B->scale, psiw.p);
+            GLF_LAUNCH_CHECK(ctx);
+            GLF_TRY(nystroem_contract(ctx, B->img, B->width, B->height, 0, N, reinterpret_cast<const float4 *>(B->samples), B->mask, B->idx, p,
+                                      coefw, B->scale, psiw.p, mq, PANEL_COLS, phip.p, 0, nullptr, nullptr));
+            GLF_TRY(scatter_sample_rows(ctx, pa.p, p, PANEL_COLS, B->idx, phip.p, 0, B->img, nullptr, mq));
+            GLF_TRY(unpack_panel(ctx, phip.p, ld, N, q, phi->data));
+        }
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GLF_OK;
+    }
     DevBuf<float> psi;
     GLF_TRY(psi.alloc(ctx, (size_t)round_up(p, NYS_PAD) * ld));
     GLF_HIP(ctx, hipMemsetAsync(psi.p, 0, sizeof(float) * (size_t)round_up(p, NYS_PAD) * ld, ctx->stream));
@@ -284,6 +366,18 @@ int glf_Permutation(glf_ctx *ctx, const glf_mat *in, const unsigned *sample_indi
     GLF_TRY(glf_memcpy_h2d(ctx, idx.p, sample_indices, sizeof(uint32_t) * num));
     GLF_TRY(glf_mat_create_dense(ctx, out, in->rows, in->cols, in->ld));
     out->row_order = GLF_ROWS_RASTER;
+    if (wide_ld((unsigned)in->ld)) { // 256-column panels
+        DevBuf<float> a, b;
+        GLF_TRY(a.alloc(ctx, (size_t)in->rows * PANEL_COLS));
+        GLF_TRY(b.alloc(ctx, (size_t)in->rows * PANEL_COLS));
+        for (unsigned q = 0; q < (unsigned)(in->ld / PANEL_COLS); ++q) {
+            GLF_TRY(pack_panel(ctx, in->data, in->ld, in->rows, q, a.p));
+            GLF_TRY(permute_rows(ctx, a.p, b.p, in->rows, PANEL_COLS, idx.p, num));
+            GLF_TRY(unpack_panel(ctx, b.p, in->ld, in->rows, q, out->data));
+        }
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GLF_OK;
+    }
     GLF_TRY(permute_rows(ctx, in->data, out->data, in->rows, (unsigned)in->ld, idx.p, num));
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;
@@ -296,10 +390,35 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
     GLF_ENTER(ctx);
     const int64_t N = (int64_t)width * height;
     const unsigned m = (unsigned)phi->cols, ld = (unsigned)phi->ld;
-    if (phi->kind != GLF_MAT_DENSE || phi->rows != N || Pi->kind != GLF_MAT_DIAG || Pi->rows != m || !valid_ld(ld))
+    if (phi->kind != GLF_MAT_DENSE || phi->rows != N || Pi->kind != GLF_MAT_DIAG || Pi->rows != m || !(valid_ld(ld) || wide_ld(ld)))
         return set_error(ctx, GLF_ERR_INVALID, "ComputeResultFromLaplacian: shape mismatch");
     if (phi->row_order == GLF_ROWS_SAMPLE_FIRST)
         return set_error(ctx, GLF_ERR_INVALID, "phi is in sample-first order: call glf_Permutation first (hpc/image_processing.c:250)");
+    if (wide_ld(ld)) { // 256-column panels: right = phi^T z panel by panel, then the correction accumulated over the panels
+        const unsigned npan = (unsigned)ceil_div(m, PANEL_COLS);
+        DevBuf<float> pan, wq, acc;
+        DevBuf<double> cq;
+        GLF_TRY(pan.alloc(ctx, (size_t)N * PANEL_COLS));
+        GLF_TRY(wq.alloc(ctx, PANEL_COLS));
+        GLF_TRY(acc.alloc(ctx, (size_t)N));
+        GLF_TRY(cq.alloc(ctx, PANEL_COLS));
+        std::vector<float> hp(m);
+        GLF_TRY(glf_memcpy_d2h(ctx, hp.data(), Pi->data, sizeof(float) * m));
+        for (unsigned q = 0; q < npan; ++q) {
+            const unsigned mq = std::min(PANEL_COLS, m - q * PANEL_COLS);
+            GLF_TRY(pack_panel(ctx, phi->data, ld, N, q, pan.p));
+            GLF_TRY(phi_t_y(ctx, pan.p, d_img, 0, N, mq, PANEL_COLS, cq.p));
+            std::vector<double> hc(PANEL_COLS);
+            std::vector<float> hw(PANEL_COLS, 0.f);
+            GLF_TRY(glf_memcpy_d2h(ctx, hc.data(), cq.p, sizeof(double) * PANEL_COLS));
+            for (unsigned j = 0; j < mq; ++j) hw[j] = (float)((double)hp[q * PANEL_COLS + j] * hc[j]);
+            GLF_TRY(glf_memcpy_h2d(ctx, wq.p, hw.data(), sizeof(float) * PANEL_COLS));
+            GLF_TRY(filter_accumulate(ctx, pan.p, 0, N, PANEL_COLS, wq.p, acc.p, q == 0));
+        }
+        GLF_TRY(filter_finish(ctx, d_img, acc.p, 0, N, gain, d_out, d_zf));
+        GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GLF_OK;
+    }
     DevBuf<double> c;
     GLF_TRY(c.alloc(ctx, ld));
     GLF_TRY(phi_t_y(ctx, phi->data, d_img, 0, N, m, ld, c.p)); // right = phi^T z, hpc/display.c:66
@@ -372,8 +491,9 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     // GetNumberEigenvalues, hpc/image_processing.c:96-108
     unsigned m = opt.num_eigvals;
     if (m == 0 || m >= p) m = p - 1;
-    if (m > 256) return set_error(ctx, GLF_ERR_UNSUPPORTED, "num_eigvals = %u > 256 not supported (p = %u)", m, p);
-    const unsigned ld = ld_for(m);
+    const bool wide = m > PANEL_COLS; // more than 256 eigenpairs (the reference default m = p - 1): 256-column panels, see below
+    if (wide && cap) return set_error(ctx, GLF_ERR_UNSUPPORTED, "glf_capture with more than 256 eigenpairs");
+    const unsigned ld = wide ? PANEL_COLS : ld_for(m);
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
     const KernelCoef coef = make_coef(opt.kernel, opt.h_loc, opt.h_val);
     int row0, row1;
@@ -413,7 +533,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     // L_A[:, r0:r1) (= its row block transposed; L_A is symmetric) and computes rows [r0,r1) of every
     // mat-vec. Otherwise (single GPU, f32 contraction, or no allgather callback) L_A is whole.
     MatShard shard;
-    const bool shard_eig = ctx->has_comm && ctx->comm.allgather_f32 && ctx->contraction == GLF_CONTRACT_F16_SPLIT;
+    const bool shard_eig = ctx->has_comm && ctx->comm.allgather_f32 && ctx->contraction == GLF_CONTRACT_F16_SPLIT && !wide;
     // For a tensor-grid sample set L_A is applied in grid-factored form and never stored (GLF_MV_PATH = grid | dense | auto;
     // auto: from 16 384 samples on -- below, streaming a small stored L_A is cheaper than the factored sweep's fixed cost)
     struct GridOpGuard {
@@ -463,6 +583,88 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     // ---- eigenpairs --------------------------------------------------------------------------
+    if (wide) {
+        // Panels of 256 vectors: the eigen-solve once (eigen.hip "panels"), then Nystroem, Phi^T y and the filter's correction
+        // one panel at a time -- only one [pixels][256] block of Phi exists at any moment.
+        const unsigned npan = (unsigned)ceil_div(m, PANEL_COLS);
+        const size_t pstride = (size_t)p32 * PANEL_COLS;
+        DevBuf<float> vecs;
+        GLF_TRY(vecs.alloc(ctx, pstride * npan));
+        std::vector<double> lamw(m);
+        int rcw = inverse_power_iteration_panels(ctx, LA.p, lda, p, m, nullptr, opt.seed, opt.opti_gs, opt.epsilon, opt.inner_rtol,
+                                                 opt.max_outer > 0 ? opt.max_outer : 100000, vecs.p, lamw.data(), &S.eig,
+                                                 shard.grid ? &shard : nullptr, dinv.p);
+        if (rcw != GLF_OK) return rcw;
+        LA.release();
+        if (eigvals_out)
+            for (unsigned j = 0; j < m; ++j) eigvals_out[j] = lamw[j];
+        GLF_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        const int64_t npixw = pix1 - pix0;
+        DevBuf<float> psiw, pinvw, phiw, ww, acc;
+        DevBuf<double> cw;
+        const size_t psi_n = (size_t)round_up(p, NYS_PAD) * PANEL_COLS;
+        GLF_TRY(psiw.alloc(ctx, psi_n));
+        GLF_TRY(pinvw.alloc(ctx, PANEL_COLS));
+        GLF_TRY(ww.alloc(ctx, PANEL_COLS));
+        GLF_TRY(cw.alloc(ctx, PANEL_COLS));
+        GLF_TRY(phiw.alloc(ctx, (size_t)npixw * PANEL_COLS));
+        GLF_TRY(acc.alloc(ctx, (size_t)npixw));
+        float *phi_basew = phiw.p - (size_t)pix0 * PANEL_COLS;
+        float kms_total = 0.f;
+        for (unsigned q = 0; q < npan; ++q) {
+            const unsigned mq = std::min(PANEL_COLS, m - q * PANEL_COLS);
+            const float *vq = vecs.p + q * pstride;
+            std::vector<float> hp(PANEL_COLS, 0.f);
+            for (unsigned j = 0; j < mq; ++j) hp[j] = (float)(1.0 / lamw[q * PANEL_COLS + j]); // InverseDiagMat, hpc/utils.c:559-586
+            GLF_HIP(ctx, hipMemcpyAsync(pinvw.p, hp.data(), sizeof(float) * PANEL_COLS, hipMemcpyHostToDevice, st));
+            GLF_HIP(ctx, hipStreamSynchronize(st));
+            GLF_HIP(ctx, hipMemsetAsync(psiw.p, 0, sizeof(float) * psi_n, st));
+            hipLaunchKernelGGL(k_make_psi, dim3((unsigned)ceil_div((int64_t)p * PANEL_COLS, 256)), dim3(256), 0, st, vq, pinvw.p, p, PANEL_COLS, mq,
+                               (float)(-alpha), psiw.p);
+            GLF_LAUNCH_CHECK(ctx);
+            GLF_HIP(ctx, hipMemsetAsync(cw.p, 0, sizeof(double) * PANEL_COLS, st));
+            float kms = 0.f;
+            uint64_t evaluated = 0;
+            GLF_TRY(nystroem_contract(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, (float)(-alpha), psiw.p,
+                                      mq, PANEL_COLS, phi_basew, 1, cw.p, &kms, opt.skip_exact_zeros, &evaluated, nullptr, &S.nystroem_path, nullptr));
+            kms_total += kms;
+            S.nystroem_evaluated += (double)evaluated;
+            {
+                unsigned i0 = 0, i1 = 0;
+                while (i0 < p && (int64_t)h_idx[i0] < pix0) ++i0;
+                i1 = i0;
+                while (i1 < p && (int64_t)h_idx[i1] < pix1) ++i1;
+                if (i1 > i0)
+                    GLF_TRY(scatter_sample_rows(ctx, vq + (size_t)i0 * PANEL_COLS, i1 - i0, PANEL_COLS, tb.idx.p + i0, phi_basew, 1, d_img, cw.p, mq));
+            }
+            GLF_TRY(allreduce_f64(ctx, cw.p, PANEL_COLS)); // right = phi^T y over all ranks' pixels (this panel's columns)
+            std::vector<double> hc(PANEL_COLS);
+            GLF_HIP(ctx, hipMemcpyAsync(hc.data(), cw.p, sizeof(double) * PANEL_COLS, hipMemcpyDeviceToHost, st));
+            GLF_HIP(ctx, hipStreamSynchronize(st));
+            std::vector<float> hw(PANEL_COLS, 0.f);
+            for (unsigned j = 0; j < mq; ++j)
+                hw[j] = (float)(std::pow(lamw[q * PANEL_COLS + j], (double)(opt.filter_pow > 0 ? opt.filter_pow : 1)) * hc[j]);
+            GLF_HIP(ctx, hipMemcpyAsync(ww.p, hw.data(), sizeof(float) * PANEL_COLS, hipMemcpyHostToDevice, st));
+            GLF_HIP(ctx, hipStreamSynchronize(st));
+            GLF_TRY(filter_accumulate(ctx, phiw.p, pix0, pix1, PANEL_COLS, ww.p, acc.p, q == 0));
+        }
+        GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+        GLF_TRY(filter_finish(ctx, d_img, acc.p, pix0, pix1, opt.gain, d_out, d_zf));
+        GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
+        GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
+        S.nystroem_launches = (int)npan;
+        S.nystroem_kernel_ms = kms_total;
+        S.contraction = ctx->contraction;
+        S.skip_exact_zeros = opt.skip_exact_zeros;
+        GLF_HIP(ctx, hipEventElapsedTime(&S.ms_affinity, ctx->ev[0], ctx->ev[1]));
+        GLF_HIP(ctx, hipEventElapsedTime(&S.ms_laplacian, ctx->ev[1], ctx->ev[2]));
+        GLF_HIP(ctx, hipEventElapsedTime(&S.ms_eigen, ctx->ev[2], ctx->ev[3]));
+        GLF_HIP(ctx, hipEventElapsedTime(&S.ms_nystroem, ctx->ev[3], ctx->ev[4]));
+        GLF_HIP(ctx, hipEventElapsedTime(&S.ms_filter, ctx->ev[4], ctx->ev[5]));
+        GLF_HIP(ctx, hipEventElapsedTime(&S.ms_total, ctx->ev[0], ctx->ev[5]));
+        if (stats) *stats = S;
+        return GLF_OK;
+    }
     DevBuf<float> phiA;
     GLF_TRY(phiA.alloc(ctx, (size_t)p32 * ld));
     std::vector<double> lam(m);

@@ -269,7 +269,8 @@ class Multi:
         opt = opt or default_options()
         out = np.zeros((h, w), dtype=np.uint8)
         zf = np.zeros((h, w), dtype=np.float32) if want_float else None
-        lam = np.zeros(4096, dtype=np.float64)
+        lam = np.zeros(max(1, int(Sampling(w, h, int(opt.num_samples) if opt.num_samples else int(h * w * opt.sample_frac)).size)),
+                       dtype=np.float64)
         stats = (Stats * self.n)()
         rc = _lib.glf_multi_image_processing(self._w, C.byref(opt), img.ctypes.data_as(C.c_void_p), C.c_int(w), C.c_int(h),
                                              out.ctypes.data_as(C.c_void_p), zf.ctypes.data_as(C.c_void_p) if want_float else None,
@@ -419,8 +420,10 @@ class Context:
         rows, cols = arr.shape
         if ld is None:
             ld = 32
-            while ld < cols:
+            while ld < min(cols, 256):
                 ld *= 2
+            if cols > 256:
+                ld = (cols + 255) // 256 * 256     # more than 256 vectors: a multiple of 256 (panels)
         mat = Mat()
         self._check(_lib.glf_mat_create_dense(self._ctx, C.byref(mat), C.c_int64(rows), C.c_int64(cols), C.c_int64(ld)))
         full = np.zeros((rows, ld), dtype=np.float32)
@@ -548,11 +551,12 @@ class Context:
                 out = torch.zeros((h, w), dtype=torch.uint8, device=self.device)
             zf = torch.zeros((h, w), dtype=torch.float32, device=self.device) if want_float else None
         st = Stats()
-        lam = np.zeros(4096, dtype=np.float64)
+        p_real = int(Sampling(w, h, int(opt.num_samples) if opt.num_samples else int(h * w * opt.sample_frac)).size)
+        lam = np.zeros(max(p_real, 1), dtype=np.float64)       # m <= p - 1 eigenvalues come back
         cap, keep = None, None
         if capture:
             # the realised sample count (hpc/sampling.c rewrites the request) and the row stride, known before the call
-            p_max = int(Sampling(w, h, int(opt.num_samples) if opt.num_samples else int(h * w * opt.sample_frac)).size)
+            p_max = p_real
             m_req = int(opt.num_eigvals) if 0 < opt.num_eigvals < p_max else max(1, p_max - 1)
             ld = 32
             while ld < min(m_req, 256):

@@ -537,9 +537,6 @@ def test_errors_are_loud(ctx):
         ctx.ComputeAffinityMatrices(d_img, np.array([5, 64 * 48], dtype=np.uint32))
     with pytest.raises(glf.GlfError):       # more samples than pixels
         ctx.image_processing(d_img, glf.default_options(num_samples=10 ** 6))
-    with pytest.raises(glf.GlfError):       # > 256 eigenpairs unsupported (stated limit)
-        big = ctx.to_device(glf.synth_image(256, 256, seed=1))
-        ctx.image_processing(big, glf.default_options(num_samples=655, num_eigvals=300))
     bad = glf.default_options()
     bad.struct_size = 8
     with pytest.raises(glf.GlfError):
@@ -611,6 +608,74 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     if paths == "grid" and info["contraction"] == glf.CONTRACT_F16_SPLIT and info["p"] >= 4:
         assert info["nystroem_path"] == 1
     _assert_end_to_end(img, ns, m, eps, out, zf, info)
+
+
+@pytest.mark.parametrize("paths", ["direct", "grid"])
+@pytest.mark.parametrize("ns,m", [(600, 0), (600, 300), (300, 257)])
+def test_more_than_256_eigenpairs_end_to_end(ctx, ns, m, paths, monkeypatch):
+    """The reference's default is m = p - 1 eigenpairs (hpc/image_processing.c:96-108; num_eigvals = 0 here): beyond 256 the
+    vectors are processed as panels of 256 columns (cross-panel terms of the classical Gram-Schmidt and of the residual as small
+    f64 GEMMs). 256 x 192 image: p = 588 -> m = 587 = panels of 256 + 256 + 75; m = 300 and m = 257 (a one-column last panel)."""
+    monkeypatch.setenv("GLF_NYS_PATH", paths)
+    monkeypatch.setenv("GLF_DEG_PATH", paths)
+    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    img = glf.synth_image(256, 192, seed=17)
+    eps = 0.2
+    p = glf.Sampling(256, 192, ns).size
+    m_eff = m if m else p - 1
+    assert m_eff > 256
+    opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    assert (info["p"], info["m"]) == (p, m_eff) and info["eigvals"].shape == (m_eff,)
+    _assert_end_to_end(img, ns, m_eff, eps, out.cpu().numpy(), zf.cpu().numpy(), info, eigvals=True)
+
+
+def test_more_than_256_vectors_stage_api(ctx):
+    """The stage API with more than 256 vectors (row-major, ld a multiple of 256): OrthonormaliseVecs / NormaliseVecs,
+    InversePowerIteration, Nystroem, Permutation, ComputeResultFromLaplacian against the oracle."""
+    n, m = 1500, 300
+    X = orc.random_vectors(n, m, 11)
+    Q_ref, norms_ref = orc.orthonormalise(X)
+    Xd = ctx.dense_from_numpy(X.T)
+    assert Xd.ld == 512
+    norms = ctx.OrthonormaliseVecs(Xd)
+    Q = ctx.mat_to_numpy(Xd).T
+    np.testing.assert_allclose(norms, norms_ref, rtol=2e-5)
+    np.testing.assert_allclose(Q, Q_ref, rtol=0, atol=2e-4 * np.abs(Q_ref).max() * np.sqrt(m))
+    np.testing.assert_allclose(Q.dot(Q.T), np.eye(m), atol=5e-5 * m)
+    Y = ctx.dense_from_numpy((X * 3.0).T)
+    np.testing.assert_allclose(ctx.NormaliseVecs(Y), 3.0 * np.linalg.norm(X, axis=1), rtol=1e-6)
+    ctx.destroy(Xd, Y)
+    # eigen-solve + extension + filter, stage by stage, m = 260 of p = 588
+    img = glf.synth_image(256, 192, seed=17)
+    h, w = img.shape
+    idx = glf.Sampling(w, h, 600)
+    p, m, eps = idx.size, 260, 0.2
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    LA, alpha = orc.laplacian(KA, orc.degree(img, idx))
+    X0 = glf.random_vectors(p, m, 1)
+    A = ctx.dense_from_numpy(LA, ld=(p + 63) // 64 * 64)
+    vecs, vals, st = ctx.InversePowerIteration(A, m, epsilon=eps, inner_rtol=1e-5, X0=X0)
+    vecs_ref, vals_ref, st_ref, free_its = parity.oracle_ipi_matching(LA, m, X0, eps, st["outer_its"], inner_rtol=1e-5)
+    assert abs(st["outer_its"] - free_its) <= 1 and st["residual"] <= eps
+    np.testing.assert_allclose(ctx.mat_to_numpy(vals), vals_ref, atol=2e-4)
+    np.testing.assert_allclose(ctx.mat_to_numpy(vecs).T, vecs_ref, atol=2e-3)
+    d_img = ctx.to_device(img)
+    _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
+    L_A, L_B, _ = ctx.ComputeLaplacianMatrix(None, K_B)
+    Pi_inv = ctx.InverseDiagMat(vals)
+    phi_sf = ctx.Nystroem(L_B, vecs, Pi_inv)
+    V = ctx.mat_to_numpy(vecs).T.astype(np.float64)
+    lam = ctx.mat_to_numpy(vals).astype(np.float64)
+    phi_sf_ref = orc.nystroem(img, idx, alpha, V, lam)
+    np.testing.assert_allclose(ctx.mat_to_numpy(phi_sf), phi_sf_ref.T, rtol=0, atol=PHI_TOL * np.abs(phi_sf_ref).max())
+    phi = ctx.Permutation(phi_sf, idx)
+    np.testing.assert_array_equal(ctx.mat_to_numpy(phi), orc.permutation(ctx.mat_to_numpy(phi_sf).T.astype(np.float64), idx).T.astype(np.float32))
+    out, zf = ctx.ComputeResultFromLaplacian(d_img, phi, vals, gain=3.0)
+    zf_ref, out_ref = orc.result_from_laplacian(img, orc.permutation(phi_sf_ref, idx), lam, gain=3.0)
+    np.testing.assert_allclose(zf.cpu().numpy(), zf_ref, rtol=0, atol=2e-2)
+    assert psnr(out.cpu().numpy(), out_ref) >= 50.0
+    ctx.destroy(A, vecs, vals, L_A, Pi_inv, phi_sf, phi, K_B)
 
 
 @pytest.mark.parametrize("w,h,ns", [(320, 1536, 30720), (1408, 200, 17600)])

@@ -152,3 +152,25 @@ def test_filter_pow_flag(tmp_path, png):
     assert psnr(out, out_ref) >= 50.0
     _, out_k1 = orc.result_from_laplacian(img, phi, vals, gain=3.0)
     assert psnr(out, out_ref) >= psnr(out, out_k1)
+
+
+@pytest.mark.gpu
+def test_reference_default_invocation_more_than_256_eigenpairs(tmp_path, png):
+    """`image_processing -f IMG` with no -num_eigvals: m = p - 1 (hpc/image_processing.c:96-108). cat_small.png with 400
+    requested samples realises p = 425, so m = 424 eigenpairs -- beyond one 256-column block; both host paths."""
+    cat = os.path.join(ROOT, "tests", "golden", "cat_small.png")
+    img = png("cat_small.png")
+    p = glf.Sampling(450, 300, 400).size
+    assert p - 1 > 256
+    _, out_ref, ref = orc.image_processing(img, 400, p - 1, epsilon=0.1, inner_rtol=1e-5, seed=1)
+    for extra in ([], ["-fused"]):
+        d = str(tmp_path / ("run" + "".join(extra)))
+        r = _run(["-f", cat, "-num_samples", "400"] + extra, d)
+        assert r.returncode == 0, r.stderr.decode()
+        assert ("Computing %d smallest eigenvalues... (epsilon: 0.1)" % (p - 1)) in r.stdout.decode()
+        out = glf.read_png(os.path.join(d, "results", "output.png"))
+        assert psnr(out, out_ref) >= 50.0
+        if not extra:
+            lam = np.loadtxt(os.path.join(d, "results", "eigenvalues_laplacian.txt"))
+            assert lam.shape == (p - 1,)
+            np.testing.assert_allclose(lam, ref["eigvals"], atol=2e-4)
