@@ -383,8 +383,14 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
 // D_A over the image rows [row0, row1): the grid-factored form when the samples are a tensor grid, else the
 // direct sweep (windowed when exact zeros may be skipped). *evaluated = kernel entries represented.
 int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
-                     unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated)
+                     unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated,
+                     const uint32_t *d_idx)
 {
+    if (coef.kernel == GLF_KERNEL_NLM) { // patch distances: no factored form, its own sweep (nlm.hip)
+        if (!d_idx) return set_error(ctx, GLF_ERR_INVALID, "NLM degree needs the device sample indices");
+        if (evaluated) *evaluated = (double)p * (double)(row1 - row0) * (double)width;
+        return nlm_degree_rows(ctx, d_img, width, height, row0, row1, d_idx, p, coef, d_degree);
+    }
     const int rc = degree_rows_grid(ctx, d_img, width, height, row0, row1, d_samples, p, h_idx, coef, d_degree, window, evaluated);
     if (rc != GLF_ERR_UNSUPPORTED) return rc;
     if (window && coef.s_loc > 0.f)
@@ -508,8 +514,13 @@ __global__ __launch_bounds__(256) void k_sample_matrix(const float4 *__restrict_
 }
 
 int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef, float *d_out,
-                        int64_t ld, bool laplacian, double alpha, const double *d_degree, unsigned col0, unsigned ncols)
+                        int64_t ld, bool laplacian, double alpha, const double *d_degree, unsigned col0, unsigned ncols,
+                        const uint8_t *d_img, int width, int height, const uint32_t *d_idx)
 {
+    if (coef.kernel == GLF_KERNEL_NLM) {
+        if (!d_img || !d_idx) return set_error(ctx, GLF_ERR_INVALID, "NLM sample matrix needs the image and the device sample indices");
+        return nlm_sample_matrix(ctx, d_img, width, height, d_idx, p, coef, d_out, ld, laplacian, alpha, d_degree, col0, ncols);
+    }
     if (ncols == 0) {
         col0 = 0;
         ncols = p;

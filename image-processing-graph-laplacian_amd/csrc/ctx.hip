@@ -386,8 +386,9 @@ KernelCoef make_coef(int kernel, float h_loc, float h_val)
 {
     const double log2e = 1.4426950408889634;
     KernelCoef c;
-    c.s_loc = (kernel == GLF_KERNEL_PHOTOMETRIC) ? 0.0f : (float)(log2e / ((double)h_loc * (double)h_loc));
+    c.s_loc = (kernel == GLF_KERNEL_PHOTOMETRIC || kernel == GLF_KERNEL_NLM) ? 0.0f : (float)(log2e / ((double)h_loc * (double)h_loc));
     c.s_val = (kernel == GLF_KERNEL_SPATIAL) ? 0.0f : (float)(log2e / ((double)h_val * (double)h_val));
+    c.kernel = kernel;
     return c;
 }
 

@@ -167,7 +167,8 @@ struct DevBuf {
 // reference exps. dr, dc, dv are exact small integers in f32.
 struct KernelCoef {
     float s_loc; // log2(e) / h_loc^2 (0 for the photometric kernel)
-    float s_val; // log2(e) / h_val^2 (0 for the spatial kernel)
+    float s_val; // log2(e) / h_val^2 (0 for the spatial kernel); NLM: log2(e) / h^2 of the patch distance
+    int kernel;  // GLF_KERNEL_*: NLM takes its own kernels (nlm.hip), the others share the positional ones
 };
 KernelCoef make_coef(int kernel, float h_loc, float h_val);
 
@@ -236,7 +237,8 @@ int mv_collect(glf_ctx *ctx);
 // device pointer to the cached start block X0 [round_up(p,64)][ld] for (p, m, ld, seed)
 int start_block_cached(glf_ctx *ctx, unsigned p, unsigned m, unsigned ld, unsigned long long seed, const float **d_block);
 int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
-                     unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated);
+                     unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated,
+                     const uint32_t *d_idx = nullptr);
 int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
                          const float4 *d_samples, unsigned p, const unsigned *h_idx, KernelCoef coef,
                          double *d_degree, double *evaluated);
@@ -249,7 +251,16 @@ int entire_computation(glf_ctx *ctx, const uint8_t *d_img, int width, int height
 // columns [col0, col0 + ncols) only (ncols = 0: all p columns); out is [p][ld] with local column index
 int build_sample_matrix(glf_ctx *ctx, const float4 *d_samples, unsigned p, KernelCoef coef,
                         float *d_out, int64_t ld, bool laplacian, double alpha, const double *d_degree,
-                        unsigned col0 = 0, unsigned ncols = 0);
+                        unsigned col0 = 0, unsigned ncols = 0, const uint8_t *d_img = nullptr, int width = 0, int height = 0,
+                        const uint32_t *d_idx = nullptr); // (image and device indices: needed by the NLM kernel only)
+// non-local-means affinity (nlm.hip): same contracts as degree_rows / build_sample_matrix / nystroem_contract
+int nlm_degree_rows(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const uint32_t *d_idx, unsigned p,
+                    KernelCoef coef, double *d_degree);
+int nlm_sample_matrix(glf_ctx *ctx, const uint8_t *d_img, int width, int height, const uint32_t *d_idx, unsigned p, KernelCoef coef,
+                      float *d_out, int64_t ld, bool laplacian, double alpha, const double *d_degree, unsigned col0, unsigned ncols);
+int nlm_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1, const uint8_t *d_mask,
+                 const uint32_t *d_idx, unsigned p, KernelCoef coef, const float *d_psi, unsigned ld, float *d_phi, int raster,
+                 double *d_c, float *kernel_ms);
 int laplacian_from_KA(glf_ctx *ctx, const float *d_KA, int64_t ldk, unsigned p, float *d_LA, int64_t ld,
                       double alpha, const double *d_degree);
 

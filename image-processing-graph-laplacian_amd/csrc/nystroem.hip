@@ -822,6 +822,11 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
         return set_error(ctx, GLF_ERR_INVALID, "nystroem_contract: bad range or ld=%u", ld);
     if (kernel_ms) *kernel_ms = 0.f;
     if (pix0 == pix1) return GLF_OK;
+    if (coef.kernel == GLF_KERNEL_NLM) { // patch distances generated on the vector pipe, f32 MFMA contraction (nlm.hip)
+        *entries_evaluated = (uint64_t)p * (uint64_t)(pix1 - pix0);
+        if (mfma_flops) *mfma_flops = 2.0 * (double)*entries_evaluated * ld;
+        return nlm_nystroem(ctx, d_img, width, height, pix0, pix1, d_mask, d_idx, p, coef, d_psi, ld, d_phi, raster, d_c, kernel_ms);
+    }
     {
         // a tensor-grid sample set (hpc/sampling.c always yields one) takes the factored contraction
         const int rc = nystroem_contract_grid(ctx, d_img, width, height, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, ld,

@@ -152,7 +152,7 @@ int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const 
                                 float h_val)
 {
     if (!ctx || !K_B || !d_img || width <= 0 || height <= 0) return GLF_ERR_INVALID;
-    if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
+    if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_NLM) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
     GLF_ENTER(ctx);
     const unsigned p = sample_size;
     SampleTables tb;
@@ -162,12 +162,12 @@ int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const 
     GLF_TRY(deg.alloc(ctx, p));
     int row0, row1;
     shard_rows(ctx, height, &row0, &row1);
-    GLF_TRY(degree_rows_auto(ctx, d_img, width, height, row0, row1, tb.samples.p, p, sample_indices, coef, deg.p, 0, nullptr));
+    GLF_TRY(degree_rows_auto(ctx, d_img, width, height, row0, row1, tb.samples.p, p, sample_indices, coef, deg.p, 0, nullptr, tb.idx.p));
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     if (K_A) {
         const int64_t lda = round_up(p, VEC_PAD);
         GLF_TRY(glf_mat_create_dense(ctx, K_A, p, p, lda)); // zero-filled incl. padding
-        GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, K_A->data, lda, false, 0.0, nullptr));
+        GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, K_A->data, lda, false, 0.0, nullptr, 0, 0, d_img, width, height, tb.idx.p));
     }
     std::memset(K_B, 0, sizeof(*K_B));
     K_B->kind = GLF_MAT_KERNEL_B;
@@ -209,7 +209,7 @@ int glf_ComputeLaplacianMatrix(glf_ctx *ctx, glf_mat *L_A, glf_mat *L_B, const g
         GLF_TRY(laplacian_from_KA(ctx, K_A->data, K_A->ld, p, L_A->data, lda, alpha, K_B->degree));
     else
         GLF_TRY(build_sample_matrix(ctx, reinterpret_cast<const float4 *>(K_B->samples), p, coef, L_A->data, lda, true,
-                                    alpha, K_B->degree));
+                                    alpha, K_B->degree, 0, 0, K_B->img, K_B->width, K_B->height, K_B->idx));
     if (L_B) { // L_B = -alpha K_B, hpc/laplacian.c:37-38: same generator, other scale (shares tables)
         *L_B = *K_B;
         L_B->scale = (float)(-alpha);
@@ -468,7 +468,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
             return set_error(ctx, GLF_ERR_INVALID, "glf_options.struct_size %u != %zu", opt_in->struct_size, sizeof(glf_options));
         opt = *opt_in;
     }
-    if (opt.kernel < GLF_KERNEL_BILATERAL || opt.kernel > GLF_KERNEL_SPATIAL) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", opt.kernel);
+    if (opt.kernel < GLF_KERNEL_BILATERAL || opt.kernel > GLF_KERNEL_NLM) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", opt.kernel);
     const int64_t N = (int64_t)width * height;
     if (N >= (int64_t)1 << 31) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too large");
     hipStream_t st = ctx->stream;
@@ -511,7 +511,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     DevBuf<double> deg;
     GLF_TRY(deg.alloc(ctx, p));
     GLF_TRY(degree_rows_auto(ctx, d_img, width, height, row0, row1, tb.samples.p, p, h_idx, coef, deg.p, opt.skip_exact_zeros,
-                             &S.degree_evaluated));
+                             &S.degree_evaluated, tb.idx.p));
     GLF_TRY(allreduce_f64(ctx, deg.p, p));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     if (cap) {
@@ -543,7 +543,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     {
         const char *mv = std::getenv("GLF_MV_PATH");
         const bool want = mv && std::strcmp(mv, "grid") == 0 ? true : mv && std::strcmp(mv, "dense") == 0 ? false : p >= 16384;
-        if (want) {
+        if (want && opt.kernel != GLF_KERNEL_NLM) {
             const int rc = grid_op_create(ctx, tb.samples.p, h_idx, p, width, height, coef, &gop.op);
             if (rc != GLF_OK && rc != GLF_ERR_UNSUPPORTED) return rc;
         }
@@ -563,7 +563,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     }
     // Exact-zero tile skipping of the mat-vec: |2^10 L_A[i][j]| = 2^10 alpha K < 2^-25 once t > 35 + log2(alpha)
     DevBuf<int4> kbox;
-    if (!gop.op && opt.skip_exact_zeros && coef.s_loc > 0.f && ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
+    if (!gop.op && opt.skip_exact_zeros && coef.s_loc > 0.f && opt.kernel != GLF_KERNEL_NLM && ctx->contraction == GLF_CONTRACT_F16_SPLIT) {
         const double t_zero = 35.5 + std::log2(alpha);
         GLF_TRY(kbox.alloc(ctx, (size_t)ceil_div(p, 64)));
         GLF_TRY(chunk_boxes(ctx, tb.samples.p, p, kbox.p));
@@ -576,7 +576,8 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     if (!gop.op) {
         GLF_TRY(LA.alloc(ctx, (size_t)p * lda));
         if (la_cols) // writes every element of the p x lda block, padding columns included
-            GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, lda, true, alpha, deg.p, shard_eig ? shard.row0 : 0u, la_cols));
+            GLF_TRY(build_sample_matrix(ctx, tb.samples.p, p, coef, LA.p, lda, true, alpha, deg.p, shard_eig ? shard.row0 : 0u, la_cols, d_img,
+                                        width, height, tb.idx.p));
     }
     GLF_TRY(dinv.alloc(ctx, p));
     hipLaunchKernelGGL(k_dinv_from_degree, dim3((p + 255) / 256), dim3(256), 0, st, deg.p, p, alpha, dinv.p);

@@ -32,7 +32,7 @@ OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_NODEVICE, ERR_COMM, ERR_NOCONV, ERR_IO, ERR_UNSUPPORTED = range(-1, -9, -1)
 MAT_DENSE, MAT_DIAG, MAT_KERNEL_B = 0, 1, 2
 ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
-KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL = 0, 1, 2
+KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL, KERNEL_NLM = 0, 1, 2, 3
 CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
 MULTI_RCCL, MULTI_LOOPBACK = 0, 1
 RCCL_ID_BYTES = 128

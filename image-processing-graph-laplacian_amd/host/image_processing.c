@@ -7,6 +7,7 @@
  *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
  *                    [-dump_eigvecs] [-ngpu N [-ngpu_backend rccl|loopback]] [-filter_pow K]
+ *                    [-kernel bilateral|photometric|spatial|nlm] [-h_loc X] [-h_val X] [-gain X]
  * -no_approx runs the full-matrix mode (hpc/image_processing.c:155-181); -use_slepc is accepted and refused.
  * -ngpu N is the reference's `mpirun -n N` (hpc/image_processing.c:30-38, 45-76): ONE process, N GPUs, one context and
  * one host thread per device, pixel rows sharded, RCCL collectives over xGMI issued by the library (glf_multi_*).
@@ -194,7 +195,7 @@ static png_bytep *EntireComputation(png_bytep *img_bytes, unsigned width, unsign
     if (glf_memcpy_h2d(ctx, d_img, flat, n) != GLF_OK) goto out;
     const double t = wtime();
     printf("Computing entire affinity matrix, Laplacian matrix and output image (matrices not stored)... ");
-    const int rc = glf_EntireComputation(ctx, (const uint8_t *)d_img, (int)width, (int)height, GLF_KERNEL_BILATERAL, stage_h_loc, stage_h_val,
+    const int rc = glf_EntireComputation(ctx, (const uint8_t *)d_img, (int)width, (int)height, stage_kernel, stage_h_loc, stage_h_val,
                                          (uint8_t *)d_out, NULL, NULL);
     if (rc != GLF_OK) {
         fprintf(stderr, "\nglf_EntireComputation: %s (%s)\n", glf_strerror(rc), glf_ctx_last_error(ctx));
@@ -222,6 +223,7 @@ static void fill_options(glf_options *opt, unsigned width, unsigned height)
     opt->num_eigvals = v ? (uint32_t)strtoul(v, NULL, 10) : 0;
     opt->opti_gs = GetOptiGramSchmidt();
     opt->epsilon = GetInverseIterationEpsilon();
+    opt->kernel = stage_kernel;
     opt->h_loc = stage_h_loc;
     opt->h_val = stage_h_val;
     opt->gain = stage_gain;
@@ -339,6 +341,19 @@ int main(int argc, char **argv)
         if ((v = opt_value("-h_loc")) && atof(v) > 0.0) stage_h_loc = (float)atof(v);
         if ((v = opt_value("-h_val")) && atof(v) > 0.0) stage_h_val = (float)atof(v);
         if ((v = opt_value("-gain"))) stage_gain = (float)atof(v);
+        if ((v = opt_value("-kernel"))) { /* bilateral (hpc/affinity.c:121) | photometric | spatial (:119-120) | nlm (python/affinity_methods/NLM.py) */
+            if (strcmp(v, "bilateral") == 0) stage_kernel = GLF_KERNEL_BILATERAL;
+            else if (strcmp(v, "photometric") == 0) stage_kernel = GLF_KERNEL_PHOTOMETRIC;
+            else if (strcmp(v, "spatial") == 0) stage_kernel = GLF_KERNEL_SPATIAL;
+            else if (strcmp(v, "nlm") == 0) {
+                stage_kernel = GLF_KERNEL_NLM;
+                if (!opt_value("-h_val")) stage_h_val = 3.0f; /* the PoC's h (NLM.py:12) */
+            } else {
+                fprintf(stderr, "-kernel %s: expected bilateral, photometric, spatial or nlm\n", v);
+                FinalizeProgram();
+                return 1;
+            }
+        }
     }
     GetFilePath(filename, sizeof(filename));
 

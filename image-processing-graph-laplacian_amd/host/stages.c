@@ -11,6 +11,7 @@
 static glf_ctx *g_world = NULL;
 /* the reference's compile-time constants, adjustable from the command line (-h_loc, -h_val, -gain) */
 float stage_h_loc = 40.0f, stage_h_val = 30.0f, stage_gain = 3.0f;
+int stage_kernel = GLF_KERNEL_BILATERAL; /* hpc/affinity.c:121 calls the bilateral kernel (the others are commented out at :119-120) */
 static glf_eig_stats g_eig_stats;
 static uint8_t *g_dimg = NULL; /* device copy of the image, uploaded once per run */
 static size_t g_dimg_bytes = 0;
@@ -95,7 +96,7 @@ int ComputeAffinityMatrices(Mat *K_A, Mat *K_B, const png_bytep *img_bytes, int 
     *K_B = new_mat();
     /* bilateral, h_loc = 40, h_val = 30: hpc/affinity.c:117-121 (stage_h_loc / stage_h_val default to those) */
     return glf_ComputeAffinityMatrices(g_world, *K_A, *K_B, d_img, width, height, sample_size, sample_indices,
-                                       GLF_KERNEL_BILATERAL, stage_h_loc, stage_h_val);
+                                       stage_kernel, stage_h_loc, stage_h_val);
 }
 
 int ComputeLaplacianMatrix(Mat *L_A, Mat *L_B, Mat K_A, Mat K_B)

@@ -138,7 +138,9 @@ int glf_memset(glf_ctx *ctx, void *dst, int value, size_t bytes);
 /* ---- matrices ----------------------------------------------------------------- */
 enum { GLF_MAT_DENSE = 0, GLF_MAT_DIAG = 1, GLF_MAT_KERNEL_B = 2 };
 enum { GLF_ROWS_NA = 0, GLF_ROWS_SAMPLE_FIRST = 1, GLF_ROWS_RASTER = 2 };
-enum { GLF_KERNEL_BILATERAL = 0, GLF_KERNEL_PHOTOMETRIC = 1, GLF_KERNEL_SPATIAL = 2 };
+/* NLM: non-local means, 7 x 7 Gaussian-weighted patches of the symmetrically padded image, K = exp(-|| G o (P_i - P_j) ||^2 / h_val^2)
+ * (python/affinity_methods/NLM.py:9-34, where h = 3; the C reference has bilateral / photometric / spatial only, hpc/affinity.c:8-121) */
+enum { GLF_KERNEL_BILATERAL = 0, GLF_KERNEL_PHOTOMETRIC = 1, GLF_KERNEL_SPATIAL = 2, GLF_KERNEL_NLM = 3 };
 
 /* Replaces PETSc Mat (MATMPIDENSE / MATMPIAIJ diagonal). */
 typedef struct glf_mat {

@@ -84,6 +84,91 @@ double orc_kernel_entry(const orc_params *prm, double r0, double c0, double v0,
     }
 }
 
+/* ---- non-local-means kernel (python/affinity_methods/NLM.py:9-34; the C reference has no NLM) --------------------
+ * K(i, j) = exp(-|| G o (patch_i - patch_j) ||^2 / h^2): 7 x 7 patches of the symmetrically padded image (np.pad 'symmetric',
+ * :16), G the 7 x 7 Gaussian mask of sigma 1.2 normalised to sum 1 (matlab_style_gauss2D + :18-19) multiplying the patch VALUES
+ * (:21-22, :29), h = prm->h_val (the PoC fixes h = 3, :12). The PoC lays its kernel row out with the pixel (row j, col i) at
+ * column i*M + j (im2col of the TRANSPOSED image, :21) and then indexes it with raster indices (python/image_processing.py:
+ * 59-64) -- consistent only where row == col; here pixel indices are raster indices throughout, and tools/gen_golden_nlm.py
+ * maps the PoC's columns back before comparing. */
+#define ORC_NLM_R 3
+#define ORC_NLM_K 49
+static void nlm_mask(double *G)
+{
+    double sum = 0.0, mx = 0.0;
+    for (int a = -ORC_NLM_R; a <= ORC_NLM_R; ++a)
+        for (int b = -ORC_NLM_R; b <= ORC_NLM_R; ++b) {
+            const double g = exp(-(double)(a * a + b * b) / (2. * 1.2 * 1.2));
+            G[(a + ORC_NLM_R) * 7 + (b + ORC_NLM_R)] = g;
+            if (g > mx) mx = g;
+        }
+    for (int k = 0; k < ORC_NLM_K; ++k) { /* h[h < eps * max] = 0, then h /= sum (python/utils.py:24-29) */
+        if (G[k] < 2.220446049250313e-16 * mx) G[k] = 0.0;
+        sum += G[k];
+    }
+    for (int k = 0; k < ORC_NLM_K; ++k) G[k] /= sum;
+    sum = 0.0;
+    for (int k = 0; k < ORC_NLM_K; ++k) sum += G[k]; /* G / np.sum(G), NLM.py:19 */
+    for (int k = 0; k < ORC_NLM_K; ++k) G[k] /= sum;
+}
+static int reflect_index(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - i - 1 : i); } /* np.pad 'symmetric' */
+
+/* F[px][k] = G[k] * padded(r + a, c + b), k = 7 (a + 3) + (b + 3) */
+static double *nlm_features(const uint8_t *img, int width, int height)
+{
+    const size_t N = (size_t)width * (size_t)height;
+    double G[ORC_NLM_K];
+    nlm_mask(G);
+    double *F = (double *)malloc(sizeof(double) * N * ORC_NLM_K);
+    if (!F) return NULL;
+#pragma omp parallel for schedule(static)
+    for (long px = 0; px < (long)N; ++px) {
+        const int r = (int)((size_t)px / (size_t)width), c = (int)((size_t)px % (size_t)width);
+        for (int a = -ORC_NLM_R; a <= ORC_NLM_R; ++a)
+            for (int b = -ORC_NLM_R; b <= ORC_NLM_R; ++b) {
+                const int k = (a + ORC_NLM_R) * 7 + (b + ORC_NLM_R);
+                F[(size_t)px * ORC_NLM_K + k] =
+                    G[k] * (double)img[(size_t)reflect_index(r + a, height) * width + reflect_index(c + b, width)];
+            }
+    }
+    return F;
+}
+
+/* One kernel entry between two PIXELS of an image, whatever the kernel: the positional kernels go through
+ * orc_kernel_entry (same doubles as before), NLM through the patch features. */
+typedef struct {
+    const orc_params *prm;
+    const uint8_t *img;
+    int width;
+    double *F; /* NLM patch features, NULL otherwise */
+} orc_pairs;
+static int pairs_init(orc_pairs *pc, const orc_params *prm, const uint8_t *img, int width, int height)
+{
+    pc->prm = prm;
+    pc->img = img;
+    pc->width = width;
+    pc->F = NULL;
+    if (prm->kernel == ORC_NLM) {
+        if (height <= 0) return -1;
+        pc->F = nlm_features(img, width, height);
+        if (!pc->F) return -1;
+    }
+    return 0;
+}
+static void pairs_free(orc_pairs *pc) { free(pc->F); pc->F = NULL; }
+static inline double pair_entry(const orc_pairs *pc, size_t a, size_t b)
+{
+    if (pc->F) {
+        const double *fa = pc->F + a * ORC_NLM_K, *fb = pc->F + b * ORC_NLM_K;
+        double d = 0.0;
+        for (int k = 0; k < ORC_NLM_K; ++k) d += (fa[k] - fb[k]) * (fa[k] - fb[k]);
+        return exp(-d / (pc->prm->h_val * pc->prm->h_val)); /* NLM.py:31 */
+    }
+    const unsigned w = (unsigned)pc->width;
+    return orc_kernel_entry(pc->prm, (double)(a / w), (double)(a % w), (double)pc->img[a], (double)(b / w), (double)(b % w),
+                            (double)pc->img[b]);
+}
+
 static uint8_t *build_sample_mask(size_t N, unsigned p, const unsigned *idx)
 {
     uint8_t *mask = (uint8_t *)calloc(N, 1);
@@ -100,27 +185,20 @@ int orc_affinity(const orc_params *prm, const uint8_t *img, int width, int heigh
                  unsigned p, const unsigned *idx, double *K_A, double *K_B)
 {
     const size_t N = (size_t)width * (size_t)height;
-    /* sample (x, y, value) vectors, hpc/affinity.c:152-178 */
-    double *sr = (double *)malloc(sizeof(double) * p * 3);
-    if (!sr) return -1;
-    double *sc = sr + p, *sv = sc + p;
-    for (unsigned j = 0; j < p; ++j) {
-        sr[j] = (double)(idx[j] / (unsigned)width); /* num2x hpc/utils.c:11 */
-        sc[j] = (double)(idx[j] % (unsigned)width); /* num2y hpc/utils.c:16 */
-        sv[j] = (double)img[idx[j]];
-    }
+    /* sample (x, y, value) vectors, hpc/affinity.c:152-178: num2x / num2y (hpc/utils.c:11-19) inside pair_entry */
+    orc_pairs pc;
+    if (pairs_init(&pc, prm, img, width, height) != 0) return -1;
     if (K_A) {
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)p; ++i) /* hpc/affinity.c:181-193 */
-            for (unsigned j = 0; j < p; ++j)
-                K_A[(size_t)i * p + j] = orc_kernel_entry(prm, sr[i], sc[i], sv[i], sr[j], sc[j], sv[j]);
+            for (unsigned j = 0; j < p; ++j) K_A[(size_t)i * p + j] = pair_entry(&pc, idx[i], idx[j]);
     }
     if (K_B) {
         /* remaining pixels in raster order, hpc/affinity.c:215-235; the
          * tmp_idx < p guard is survey quirk Q2 (OOB read at :222). */
         const size_t R = N - p;
         unsigned *rem = (unsigned *)malloc(sizeof(unsigned) * (R ? R : 1));
-        if (!rem) { free(sr); return -1; }
+        if (!rem) { pairs_free(&pc); return -1; }
         size_t tmp_idx = 0, k = 0;
         for (size_t j = 0; j < N; ++j) {
             if (tmp_idx < p && j == idx[tmp_idx]) ++tmp_idx;
@@ -128,16 +206,10 @@ int orc_affinity(const orc_params *prm, const uint8_t *img, int width, int heigh
         }
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)p; ++i) /* hpc/affinity.c:239-250 */
-            for (size_t c = 0; c < R; ++c) {
-                const unsigned px = rem[c];
-                K_B[(size_t)i * R + c] = orc_kernel_entry(prm, sr[i], sc[i], sv[i],
-                                                          (double)(px / (unsigned)width),
-                                                          (double)(px % (unsigned)width),
-                                                          (double)img[px]);
-            }
+            for (size_t c = 0; c < R; ++c) K_B[(size_t)i * R + c] = pair_entry(&pc, idx[i], rem[c]);
         free(rem);
     }
-    free(sr);
+    pairs_free(&pc);
     return 0;
 }
 
@@ -149,22 +221,21 @@ int orc_degree(const orc_params *prm, const uint8_t *img, int width, int height,
     if (row0 < 0 || row1 > height || row0 > row1) return -1;
     uint8_t *mask = build_sample_mask(N, p, idx);
     if (!mask) return -1;
+    orc_pairs pc;
+    if (pairs_init(&pc, prm, img, width, height) != 0) { free(mask); return -1; }
 #pragma omp parallel for schedule(dynamic, 8)
     for (long i = 0; i < (long)p; ++i) {
-        const double r0 = (double)(idx[i] / (unsigned)width);
-        const double c0 = (double)(idx[i] % (unsigned)width);
-        const double v0 = (double)img[idx[i]];
         double sumA = 0.0, sumB = 0.0;
         for (int r = row0; r < row1; ++r) {
-            const uint8_t *row = img + (size_t)r * width;
             const uint8_t *mrow = mask + (size_t)r * width;
             for (int c = 0; c < width; ++c) {
-                const double k = orc_kernel_entry(prm, r0, c0, v0, (double)r, (double)c, (double)row[c]);
+                const double k = pair_entry(&pc, idx[i], (size_t)r * width + c);
                 if (mrow[c]) sumA += k; else sumB += k;
             }
         }
         D[i] = sumA + sumB;
     }
+    pairs_free(&pc);
     free(mask);
     return 0;
 }
@@ -449,15 +520,11 @@ int orc_nystroem(const orc_params *prm, const uint8_t *img, int width, int heigh
     if (!pos) return -1;
     /* part_lower = phi_A * Pi^-1 (:41), stored row-major p x m */
     double *PL = (double *)malloc(sizeof(double) * (size_t)p * m);
-    double *sr = (double *)malloc(sizeof(double) * p * 3);
-    double *sc = sr + p, *sv = sc + p;
-    for (unsigned i = 0; i < p; ++i) {
-        sr[i] = (double)(idx[i] / (unsigned)width);
-        sc[i] = (double)(idx[i] % (unsigned)width);
-        sv[i] = (double)img[idx[i]];
+    orc_pairs pc;
+    if (!PL || pairs_init(&pc, prm, img, width, height) != 0) { free(PL); free(pos); return -1; }
+    for (unsigned i = 0; i < p; ++i)
         for (unsigned j = 0; j < m; ++j)
             PL[(size_t)i * m + j] = phi_A[(size_t)j * p + i] * (1. / eigvals[j]); /* InverseDiagMat hpc/utils.c:559-586 */
-    }
     /* upper part (:25-34) */
     for (unsigned j = 0; j < m; ++j)
         memcpy(phi + (size_t)j * N, phi_A + (size_t)j * p, sizeof(double) * p);
@@ -469,12 +536,9 @@ int orc_nystroem(const orc_params *prm, const uint8_t *img, int width, int heigh
         for (long px = 0; px < (long)N; ++px) {
             const unsigned q = pos[px];
             if (q < p) continue;
-            const double r = (double)((unsigned)px / (unsigned)width);
-            const double c = (double)((unsigned)px % (unsigned)width);
-            const double v = (double)img[px];
             for (unsigned j = 0; j < m; ++j) acc[j] = 0.0;
             for (unsigned i = 0; i < p; ++i) {
-                const double lb = -alpha * orc_kernel_entry(prm, sr[i], sc[i], sv[i], r, c, v);
+                const double lb = -alpha * pair_entry(&pc, idx[i], (size_t)px);
                 const double *pl = PL + (size_t)i * m;
                 for (unsigned j = 0; j < m; ++j) acc[j] += lb * pl[j];
             }
@@ -482,7 +546,8 @@ int orc_nystroem(const orc_params *prm, const uint8_t *img, int width, int heigh
         }
         free(acc);
     }
-    free(sr); free(PL); free(pos);
+    pairs_free(&pc);
+    free(PL); free(pos);
     return 0;
 }
 
@@ -613,6 +678,7 @@ int orc_entire_computation(const orc_params *prm, const uint8_t *img, int width,
                            double *zf, uint8_t *out)
 {
     const size_t N = (size_t)width * (size_t)height;
+    if (prm->kernel == ORC_NLM) return -1; /* (the full-matrix mode exists for the positional kernels only) */
     double *D = (double *)malloc(sizeof(double) * N);
     double *Ky = (double *)malloc(sizeof(double) * N);
     if (!D || !Ky) return -1;
@@ -651,20 +717,19 @@ int orc_entire_computation(const orc_params *prm, const uint8_t *img, int width,
 
 /* Rows [i0,i1) of L_A = alpha (diag(D) - K_A) straight from the samples
  * (hpc/affinity.c:181-193 + hpc/laplacian.c:31-35). out: (i1-i0) x p row-major. */
-int orc_laplacian_rows(const orc_params *prm, const uint8_t *img, int width, unsigned p, const unsigned *idx,
+int orc_laplacian_rows(const orc_params *prm, const uint8_t *img, int width, int height, unsigned p, const unsigned *idx,
                        const double *D, double alpha, unsigned i0, unsigned i1, double *out)
 {
     if (i0 > i1 || i1 > p) return -1;
+    orc_pairs pc;
+    if (pairs_init(&pc, prm, img, width, height) != 0) return -1;
 #pragma omp parallel for schedule(static)
-    for (long i = i0; i < (long)i1; ++i) {
-        const double r0 = (double)(idx[i] / (unsigned)width), c0 = (double)(idx[i] % (unsigned)width);
-        const double v0 = (double)img[idx[i]];
+    for (long i = i0; i < (long)i1; ++i)
         for (unsigned j = 0; j < p; ++j) {
-            const double k = orc_kernel_entry(prm, r0, c0, v0, (double)(idx[j] / (unsigned)width),
-                                              (double)(idx[j] % (unsigned)width), (double)img[idx[j]]);
+            const double k = pair_entry(&pc, idx[i], idx[j]);
             out[(size_t)(i - i0) * p + j] = (-1.0 * k + (((unsigned)i == j) ? D[i] : 0.0)) * alpha;
         }
-    }
+    pairs_free(&pc);
     return 0;
 }
 
@@ -705,25 +770,19 @@ int orc_nystroem_rows(const orc_params *prm, const uint8_t *img, int width, int 
     if (row0 < 0 || row1 > height || row0 > row1) return -1;
     const size_t npix = (size_t)(row1 - row0) * width;
     double *PL = (double *)malloc(sizeof(double) * (size_t)p * m);
-    double *sr = (double *)malloc(sizeof(double) * p * 3);
-    if (!PL || !sr) return -1;
-    double *sc = sr + p, *sv = sc + p;
-    for (unsigned i = 0; i < p; ++i) {
-        sr[i] = (double)(idx[i] / (unsigned)width);
-        sc[i] = (double)(idx[i] % (unsigned)width);
-        sv[i] = (double)img[idx[i]];
+    orc_pairs pc;
+    if (!PL || pairs_init(&pc, prm, img, width, height) != 0) { free(PL); return -1; }
+    for (unsigned i = 0; i < p; ++i)
         for (unsigned j = 0; j < m; ++j) PL[(size_t)i * m + j] = phi_A[(size_t)j * p + i] * (1. / eigvals[j]);
-    }
 #pragma omp parallel
     {
         double *acc = (double *)malloc(sizeof(double) * (m ? m : 1));
 #pragma omp for schedule(dynamic, 16)
         for (long q = 0; q < (long)npix; ++q) {
             const size_t px = (size_t)row0 * width + (size_t)q;
-            const double r = (double)(px / (unsigned)width), c = (double)(px % (unsigned)width), v = (double)img[px];
             for (unsigned j = 0; j < m; ++j) acc[j] = 0.0;
             for (unsigned i = 0; i < p; ++i) {
-                const double lb = -alpha * orc_kernel_entry(prm, sr[i], sc[i], sv[i], r, c, v);
+                const double lb = -alpha * pair_entry(&pc, idx[i], px);
                 const double *pl = PL + (size_t)i * m;
                 for (unsigned j = 0; j < m; ++j) acc[j] += lb * pl[j];
             }
@@ -731,7 +790,7 @@ int orc_nystroem_rows(const orc_params *prm, const uint8_t *img, int width, int 
         }
         free(acc);
     }
-    free(sr);
+    pairs_free(&pc);
     free(PL);
     return 0;
 }

@@ -37,7 +37,8 @@ extern "C" {
 
 /* Kernel selector (hpc/affinity.c:117-121 picks bilateral; the other two are the
  * commented-out alternatives hpc/affinity.c:8-57). */
-enum { ORC_BILATERAL = 0, ORC_PHOTOMETRIC = 1, ORC_SPATIAL = 2 };
+/* ORC_NLM: non-local means, 7 x 7 Gaussian-weighted patches (python/affinity_methods/NLM.py:9-34), h = h_val */
+enum { ORC_BILATERAL = 0, ORC_PHOTOMETRIC = 1, ORC_SPATIAL = 2, ORC_NLM = 3 };
 
 typedef struct orc_params {
     double h_loc;   /* 40.0  hpc/affinity.c:118 */
@@ -159,7 +160,7 @@ int orc_entire_computation(const orc_params *prm, const uint8_t *img, int width,
                            double *zf, uint8_t *out);
 
 /* Bounded-sample helpers for bench.py's cpu_baseline leg (same arithmetic on a slice). */
-int orc_laplacian_rows(const orc_params *prm, const uint8_t *img, int width, unsigned p, const unsigned *idx,
+int orc_laplacian_rows(const orc_params *prm, const uint8_t *img, int width, int height, unsigned p, const unsigned *idx,
                        const double *D, double alpha, unsigned i0, unsigned i1, double *out);
 int orc_matvec_rows(const double *Arows, unsigned nrows, unsigned p, const double *X, unsigned m, double *Y);
 int orc_nystroem_rows(const orc_params *prm, const uint8_t *img, int width, int height, int row0, int row1,

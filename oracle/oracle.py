@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-BILATERAL, PHOTOMETRIC, SPATIAL = 0, 1, 2
+BILATERAL, PHOTOMETRIC, SPATIAL, NLM = 0, 1, 2, 3
 
 
 class Params(C.Structure):
@@ -252,7 +252,7 @@ def laplacian_rows(img, idx, D, alpha, i0, i1, prm=None):
     idx = np.ascontiguousarray(idx, dtype=np.uint32)
     D = np.ascontiguousarray(D, dtype=np.float64)
     out = np.empty((i1 - i0, idx.size))
-    rc = lib().orc_laplacian_rows(C.byref(prm), _p(img, C.c_uint8), img.shape[1], C.c_uint(idx.size),
+    rc = lib().orc_laplacian_rows(C.byref(prm), _p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_uint(idx.size),
                                   _p(idx, C.c_uint), _p(D), C.c_double(alpha), C.c_uint(i0), C.c_uint(i1), _p(out))
     assert rc == 0
     return out

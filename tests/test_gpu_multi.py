@@ -94,3 +94,12 @@ def test_rccl_init_rank_on_a_context():
         np.testing.assert_allclose(zf.cpu().numpy(), zf1, rtol=0, atol=5e-4)
     with pytest.raises(glf.GlfError):
         glf.Multi(2, devices=[0, 0], backend=glf.MULTI_RCCL)       # RCCL refuses one device twice: loud, not a hang
+
+
+def test_loopback_two_ranks_nlm_kernel():
+    """The non-local-means affinity through the sharded path: degree partial sums per rank, L_A column blocks generated by
+    k_nlm_matrix(col0, ncols), row-sharded eigen-solve, Nystroem per pixel-row shard."""
+    img = glf.synth_image(96, 80, seed=4)
+    opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
+    opt.kernel, opt.h_val = glf.KERNEL_NLM, 3.0
+    _check(img, opt, 2, glf.MULTI_LOOPBACK, [0, 0])

@@ -610,6 +610,61 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     _assert_end_to_end(img, ns, m, eps, out, zf, info)
 
 
+def test_nlm_kernel_stages_against_golden_and_oracle(ctx, golden):
+    """Non-local means (python/affinity_methods/NLM.py:9-34): K_A against the PoC's kernel rows, D_A, L_A, the Nystroem
+    contraction and the filter against the oracle, through the stage API (hpc/affinity.h:5 with kernel = GLF_KERNEL_NLM)."""
+    g = golden("nlm.npz")
+    prm = orc.default_params(orc.NLM)
+    prm.h_val = 3.0
+    for tag, m in (("syn32", 4), ("rect", 3)):
+        img, idx, K = g[tag + "_img"], g[tag + "_idx"], g[tag + "_K"]
+        h, w = img.shape
+        p = idx.size
+        d_img = ctx.to_device(img)
+        K_A, K_B = ctx.ComputeAffinityMatrices(d_img, idx, kernel=glf.KERNEL_NLM, h_val=3.0)
+        got = ctx.mat_to_numpy(K_A).astype(np.float64)
+        ref = K[:, idx]
+        big = ref >= 1e-6
+        np.testing.assert_allclose(got[big], ref[big], rtol=5e-6)            # f32 patch distances, one v_exp_f32
+        np.testing.assert_allclose(got, ref, rtol=3e-4, atol=1e-37)
+        D_ref = K.sum(1)
+        np.testing.assert_allclose(ctx.degree_of(K_B), D_ref, rtol=3e-6)
+        L_A, L_B, alpha = ctx.ComputeLaplacianMatrix(K_A, K_B)
+        LA_ref, alpha_ref = orc.laplacian(ref, D_ref)
+        assert alpha == pytest.approx(alpha_ref, rel=3e-6)
+        np.testing.assert_allclose(ctx.mat_to_numpy(L_A), LA_ref, rtol=0, atol=5e-6 * np.abs(LA_ref).max())
+        L_A2, _, _ = ctx.ComputeLaplacianMatrix(None, K_B)                   # regenerated entries (k_nlm_matrix, Laplacian form)
+        np.testing.assert_allclose(ctx.mat_to_numpy(L_A2), LA_ref, rtol=0, atol=5e-6 * np.abs(LA_ref).max())
+        vecs, vals = _lapack_pairs(LA_ref, m)
+        phi_sf_ref = orc.nystroem(img, idx, alpha_ref, vecs, vals, prm=prm)
+        phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
+        Pi_inv = ctx.InverseDiagMat(Pi)
+        phi_sf = ctx.Nystroem(L_B, phi_A, Pi_inv)
+        np.testing.assert_allclose(ctx.mat_to_numpy(phi_sf), phi_sf_ref.T, rtol=0, atol=PHI_TOL * np.abs(phi_sf_ref).max())
+        phi = ctx.Permutation(phi_sf, idx)
+        out, zf = ctx.ComputeResultFromLaplacian(d_img, phi, Pi, gain=3.0)
+        zf_ref, out_ref = orc.result_from_laplacian(img, orc.permutation(phi_sf_ref, idx), vals, gain=3.0)
+        np.testing.assert_allclose(zf.cpu().numpy(), zf_ref, rtol=0, atol=2e-2)
+        assert psnr(out.cpu().numpy(), out_ref) >= 50.0
+        ctx.destroy(K_A, L_A, L_A2, phi_A, Pi, Pi_inv, phi_sf, phi, K_B)
+
+
+@pytest.mark.parametrize("w,h,ns,m", [(96, 80, 60, 8), (53, 37, 20, 5), (160, 128, 300, 40)])
+def test_nlm_kernel_end_to_end(ctx, w, h, ns, m):
+    """The whole path with the non-local-means affinity (glf_options.kernel = GLF_KERNEL_NLM, h_val = 3 as in the PoC) against
+    the oracle: degree sweep, stored L_A, eigen-solve, f32-MFMA Nystroem contraction with patch distances generated in
+    registers, filter. 160 x 128 with 300 requested samples: several 64-sample chunks and a ragged last one."""
+    img = glf.synth_image(w, h, seed=23)
+    prm = orc.default_params(orc.NLM)
+    prm.h_val = 3.0
+    eps = 0.1
+    opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    opt.kernel, opt.h_val = glf.KERNEL_NLM, 3.0
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    assert info["nystroem_path"] == 0 and info["matvec_path"] == 0         # no factored form exists for patch distances
+    _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info, eigvals=True, prm=prm)
+
+
 @pytest.mark.parametrize("paths", ["direct", "grid"])
 @pytest.mark.parametrize("ns,m", [(600, 0), (600, 300), (300, 257)])
 def test_more_than_256_eigenpairs_end_to_end(ctx, ns, m, paths, monkeypatch):

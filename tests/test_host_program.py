@@ -174,3 +174,19 @@ def test_reference_default_invocation_more_than_256_eigenpairs(tmp_path, png):
             lam = np.loadtxt(os.path.join(d, "results", "eigenvalues_laplacian.txt"))
             assert lam.shape == (p - 1,)
             np.testing.assert_allclose(lam, ref["eigvals"], atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_kernel_flag_nlm(tmp_path, png):
+    """-kernel nlm: the PoC's non-local-means affinity (h = 3 unless -h_val is given) through the C host, both paths."""
+    img = png("test.png")
+    prm = orc.default_params(orc.NLM)
+    prm.h_val = 3.0
+    _, out_ref, _ = orc.image_processing(img, 100, 12, epsilon=0.1, inner_rtol=1e-5, seed=1, prm=prm)
+    for extra in ([], ["-fused"]):
+        d = str(tmp_path / ("k" + "".join(extra)))
+        r = _run(["-f", TEST_PNG, "-num_eigvals", "12", "-kernel", "nlm"] + extra, d)
+        assert r.returncode == 0, r.stderr.decode()
+        assert psnr(glf.read_png(os.path.join(d, "results", "output.png")), out_ref) >= 50.0
+    bad = _run(["-f", TEST_PNG, "-kernel", "gabor"], str(tmp_path))
+    assert bad.returncode == 1 and b"expected bilateral, photometric, spatial or nlm" in bad.stderr

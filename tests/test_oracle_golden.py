@@ -291,3 +291,25 @@ def test_bounded_sample_helpers_agree_with_full_stages(golden):
     mask = np.ones((32, 32), dtype=bool)
     mask.reshape(-1)[idx] = False
     np.testing.assert_allclose(part[:, mask[10:14]], full[:, 10:14][:, mask[10:14]], rtol=1e-12)
+
+
+def test_nlm_kernel_against_the_poc(golden):
+    """The non-local-means affinity (python/affinity_methods/NLM.py:9-34; f1 of SURVEY 8f): the oracle's restatement against
+    the PoC's kernel rows (tools/gen_golden_nlm.py re-indexes the PoC's transposed column layout to raster order) on a square
+    and on a non-square image -- symmetric padding, the sum-normalised 7 x 7 Gaussian mask on the patch VALUES, h = 3."""
+    g = golden("nlm.npz")
+    for tag in ("syn32", "rect"):
+        img, idx, K = g[tag + "_img"], g[tag + "_idx"], g[tag + "_K"]
+        h, w = img.shape
+        prm = orc.default_params(orc.NLM)
+        prm.h_val = 3.0
+        KA, KB = orc.affinity(img, idx, prm=prm)
+        rest = np.ones(h * w, dtype=bool)
+        rest[idx] = False
+        np.testing.assert_allclose(KA, K[:, idx], rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(KB, K[:, rest], rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(np.diag(KA), 1.0, rtol=0, atol=0)
+        np.testing.assert_allclose(orc.degree(img, idx, prm=prm), K.sum(1), rtol=1e-13)
+        D = K.sum(1)
+        LA, alpha = orc.laplacian(KA, D)
+        np.testing.assert_allclose(orc.laplacian_rows(img, idx, D, alpha, 2, 5, prm=prm), LA[2:5], rtol=1e-13, atol=1e-300)
