@@ -295,7 +295,7 @@ def main():
     # the "true dense contraction" of north_star, SURVEY 8d's W_nys = 2 (N - p) p m) so that it has a driver-timed number
     direct_leg = None
     if not args.no_direct_leg and info["nystroem_path"] == 1:
-        os.environ["GLF_NYS_PATH"] = "direct"
+        ctx.set_tuning(NYS_PATH="direct")
         try:
             ctx.image_processing(d_img, opt, out=d_out)          # warm-up (tables, pool)
             barrier()
@@ -303,7 +303,7 @@ def main():
             barrier()
             direct_leg = dinfo
         finally:
-            del os.environ["GLF_NYS_PATH"]
+            ctx.set_tuning(NYS_PATH=None)
 
     # parity leg input: one more (untimed) run of the headline configuration with its by-products captured
     cap_run = None

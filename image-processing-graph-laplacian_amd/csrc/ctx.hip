@@ -74,7 +74,45 @@ int glf_ctx_create(glf_ctx **out, int device, void *hip_stream)
         else fprintf(stderr, "glf: ignoring GLF_CONTRACTION=%s (expected f32 or f16s)\n", mode);
     }
     if (const char *dbg = std::getenv("GLF_POOL_DEBUG")) ctx->pool_debug = dbg[0] && dbg[0] != '0';
+    for (const char *key : {"NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "NYS_NO_LUT", "NO_ECR", "GS", "RESIDUAL", "VERBOSE"}) {
+        char name[32];
+        std::snprintf(name, sizeof(name), "GLF_%s", key);
+        if (const char *v = std::getenv(name))
+            if (glf_ctx_set_tuning(ctx, key, v) != GLF_OK) fprintf(stderr, "glf: ignoring %s=%s\n", name, v);
+    }
     *out = ctx;
+    return GLF_OK;
+}
+
+int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value)
+{
+    if (!ctx || !key) return GLF_ERR_INVALID;
+    const bool unset = !value || !value[0] || !std::strcmp(value, "auto") || !std::strcmp(value, "default");
+    auto is = [&](const char *s) { return value && !std::strcmp(value, s); };
+    auto flag = [&]() { return !unset && !is("0"); };
+    glf_tuning &t = ctx->tune;
+    if (!std::strcmp(key, "NYS_PATH") || !std::strcmp(key, "DEG_PATH")) {
+        if (!unset && !is("grid") && !is("direct")) return GLF_ERR_INVALID;
+        (key[0] == 'N' ? t.nys_path : t.deg_path) = unset ? 0 : is("grid") ? 1 : 2;
+    } else if (!std::strcmp(key, "MV_PATH")) {
+        if (!unset && !is("grid") && !is("dense")) return GLF_ERR_INVALID;
+        t.mv_path = unset ? 0 : is("grid") ? 1 : 2;
+    } else if (!std::strcmp(key, "ROWPASS")) {
+        if (!unset && !is("rt") && !is("v1")) return GLF_ERR_INVALID;
+        t.rowpass = is("v1") ? 1 : 0;
+    } else if (!std::strcmp(key, "ROWPASS_OP")) {
+        if (!unset && !is("rt") && !is("v1")) return GLF_ERR_INVALID;
+        t.rowpass_op = is("rt") ? 1 : 0;
+    } else if (!std::strcmp(key, "NYS_NO_LUT")) t.nys_no_lut = flag();
+    else if (!std::strcmp(key, "NO_ECR")) t.no_ecr = flag();
+    else if (!std::strcmp(key, "GS")) {
+        if (!unset && !is("seq") && !is("gram")) return GLF_ERR_INVALID;
+        t.gs_seq = is("seq");
+    } else if (!std::strcmp(key, "RESIDUAL")) {
+        if (!unset && !is("sweep") && !is("derived")) return GLF_ERR_INVALID;
+        t.residual_sweep = is("sweep");
+    } else if (!std::strcmp(key, "VERBOSE")) t.verbose = flag();
+    else return GLF_ERR_INVALID;
     return GLF_OK;
 }
 

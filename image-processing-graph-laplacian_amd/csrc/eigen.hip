@@ -1441,16 +1441,15 @@ static int orthonormalise_dev(glf_ctx *ctx, GsWork &w, float *X, unsigned n, uns
 {
     if (!rows.dist) rows.r1 = n, rows.r0 = 0;
     if (replicated) *replicated = false;
-    const char *mode = std::getenv("GLF_GS");
     w.last_fused = false;
-    if (!(mode && std::strcmp(mode, "seq") == 0)) {
+    if (!ctx->tune.gs_seq) {
         int fell_back = 0;
         GLF_TRY(orthonormalise_fused_dev(ctx, w.fused, X, rows, m, ld, w.norms.p, &fell_back));
         if (!fell_back) {
             w.last_fused = true;
             return GLF_OK;
         }
-        if (std::getenv("GLF_VERBOSE")) fprintf(stderr, "[glf] Gram-Schmidt: ill-conditioned block, column-by-column sweep\n");
+        if (ctx->tune.verbose) fprintf(stderr, "[glf] Gram-Schmidt: ill-conditioned block, column-by-column sweep\n");
     }
     if (rows.dist) {
         GLF_TRY(allgather_rows(ctx, X, shard, ld));
@@ -1728,11 +1727,10 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
     double r_norm = 0.0;
     GLF_TRY(residual_dev(ctx, rs, A, lda, p, X.p, m, ld, &r_norm)); // :159
-    const bool verbose = std::getenv("GLF_VERBOSE") != nullptr; // the reference logs every outer iteration (:164-181)
+    const bool verbose = ctx->tune.verbose; // the reference logs every outer iteration (:164-181)
     if (verbose) fprintf(stderr, "[glf rank %d] initial residual %.9g\n", ctx->comm.rank, r_norm);
     int it = 0, inner_total = 0, rc = GLF_OK;
-    const char *res_mode = std::getenv("GLF_RESIDUAL");
-    const bool derive_ax = !(res_mode && std::strcmp(res_mode, "sweep") == 0);
+    const bool derive_ax = !ctx->tune.residual_sweep;
     while (r_norm > epsilon) { // :161
         if (it >= max_outer) {
             rc = set_error(ctx, GLF_ERR_NOCONV, "inverse iteration: residual %g > %g after %d outer iterations", r_norm,
@@ -1930,7 +1928,7 @@ int inverse_power_iteration_panels(glf_ctx *ctx, const float *A, int64_t lda, un
     GLF_HIP(ctx, hipMemcpyAsync(Xb.p, X.p, sizeof(float) * total, hipMemcpyDeviceToDevice, st));
     double r_norm = 0.0;
     GLF_TRY(panels_residual(ctx, pw, A, lda, p, X.p, AX.p, pstride, m, shard, &r_norm)); // :159
-    const bool verbose = std::getenv("GLF_VERBOSE") != nullptr;
+    const bool verbose = ctx->tune.verbose;
     if (verbose) fprintf(stderr, "[glf] %u panels; initial residual %.9g\n", npan, r_norm);
     int it = 0, inner_total = 0, rc = GLF_OK;
     while (r_norm > epsilon) { // :161

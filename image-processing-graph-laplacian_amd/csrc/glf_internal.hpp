@@ -22,6 +22,22 @@ struct glf_pool_block {
     bool in_use;
 };
 
+// Which of several equivalent kernels implements a stage. Defaults (0 / false) = chosen from the problem size; every choice
+// computes the same sums and is tested against the oracle and against the others. Set with glf_ctx_set_tuning, initialised at
+// context creation from the environment variables GLF_<KEY> (read once, never per call).
+struct glf_tuning {
+    int nys_path = 0;            // NYS_PATH: 0 auto, 1 grid (factored Nystroem), 2 direct (entry by entry)
+    int deg_path = 0;            // DEG_PATH: likewise for the degree
+    int mv_path = 0;             // MV_PATH: 0 auto, 1 grid (L_A applied in factored form), 2 dense (stored L_A)
+    int rowpass = 0;             // ROWPASS: row pass of the Nystroem passes: 0 / rt = row-tile form, 1 / v1 = one image row per wave
+    int rowpass_op = 0;          // ROWPASS_OP: row pass of the L_A sweeps: 0 / v1, 1 / rt
+    bool nys_no_lut = false;     // NYS_NO_LUT: direct Nystroem kernel generates entries with v_exp_f32 instead of LDS tables
+    bool no_ecr = false;         // NO_ECR: column pass reads the per-column Ec fragment table instead of the compact one
+    bool gs_seq = false;         // GS=seq: Gram-Schmidt as the column-by-column sweep instead of the Gram-matrix form
+    bool residual_sweep = false; // RESIDUAL=sweep: residual from an explicit L_A sweep instead of the PCG state
+    bool verbose = false;        // VERBOSE: log every outer iteration on stderr (the reference does, hpc/inverse_power_it.c:164-181)
+};
+
 struct glf_native_comm; // comm.hip: RCCL / loopback communicator owned by a context
 
 struct glf_ctx {
@@ -57,6 +73,7 @@ struct glf_ctx {
     // debug pool (GLF_POOL_DEBUG=1): exact-size blocks + guard zone, NaN-filled floating-point buffers, no reuse
     bool pool_debug = false;
     int pool_violations = 0;
+    glf_tuning tune;
 };
 
 namespace glf {

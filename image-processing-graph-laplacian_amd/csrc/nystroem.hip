@@ -589,13 +589,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8
                 sv[0] = v0.x; sv[1] = v0.y; sv[2] = v0.z; sv[3] = v0.w; sv[4] = v1.x; sv[5] = v1.y; sv[6] = v1.z; sv[7] = v1.w;
             }
             f16x8 ah[PB], al[PB];
-#ifdef NYS_DBG_NOGEN
-#pragma unroll
-            for (int b = 0; b < PB; ++b)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ah[b][e] = (_Float16)pv[b]; al[b][e] = (_Float16)pc[b]; }
-            if (0)
-#endif
 #pragma unroll
             for (int b = 0; b < PB; ++b) {
 #pragma unroll
@@ -627,27 +620,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8
             }
             // The two waves of a SIMD drift into lockstep (both generating, then both contracting) unless the
             // one in its MFMA burst wins the issue arbitration: the other then fills the gaps with its VALU.
-#ifndef NYS_DBG_NO_SETPRIO
             __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int j = 0; j < MB; ++j) {
                 const f16x8 bh = sfrag[((t * MB + j) * 2 + 0) * 64 + lane];
                 const f16x8 bl = sfrag[((t * MB + j) * 2 + 1) * 64 + lane];
 #pragma unroll
                 for (int b = 0; b < PB; ++b) {
-#ifdef NYS_DBG_NOMFMA
-                    asm volatile("" : : "v"(ah[b]), "v"(al[b]), "v"(bh), "v"(bl));
-#else
                     acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bh, acc[b][j], 0, 0, 0);
                     acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], bl, acc[b][j], 0, 0, 0);
                     acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b], bh, acc[b][j], 0, 0, 0);
-#endif
                 }
             }
-#ifndef NYS_DBG_NO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         }
         lds_dma_drain(); // this wave's pieces of the next chunk have landed ...
         __syncthreads(); // ... and so have everybody else's; buffer `buf` is free again
@@ -748,7 +733,7 @@ static int launch_nystroem_f16s(glf_ctx *ctx, const uint8_t *d_img, int width, i
     // row, a spatial factor that reaches exact zero within NYS_LUT_RMAX, and LDS for two workgroups per CU.
     constexpr int NW_LUT = 8;
     int lut_r = 0;
-    if (MB <= 2 && coef.s_loc > 0.f && width % (32 * PB) == 0 && pix0 % (32 * PB) == 0 && !getenv("GLF_NYS_NO_LUT")) {
+    if (MB <= 2 && coef.s_loc > 0.f && width % (32 * PB) == 0 && pix0 % (32 * PB) == 0 && !ctx->tune.nys_no_lut) {
         // exp2(-s d^2) < 2^-150 rounds to +0 in f32
         lut_r = (int)std::floor(std::sqrt(150.5 / (double)coef.s_loc)) + 1;
         if (lut_r > NYS_LUT_RMAX) lut_r = 0;

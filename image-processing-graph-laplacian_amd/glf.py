@@ -40,7 +40,7 @@ RCCL_ID_BYTES = 128
 # every symbol include/glf.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
-    "glf_ctx_device_info", "glf_ctx_set_comm", "glf_rccl_unique_id", "glf_ctx_set_comm_rccl", "glf_multi_create", "glf_multi_destroy",
+    "glf_ctx_device_info", "glf_ctx_set_tuning", "glf_ctx_set_comm", "glf_rccl_unique_id", "glf_ctx_set_comm_rccl", "glf_multi_create", "glf_multi_destroy",
     "glf_multi_size", "glf_multi_ctx", "glf_multi_last_error", "glf_multi_image_processing", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
     "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_mat_get_column", "glf_Sampling",
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
@@ -326,6 +326,18 @@ class Context:
 
     def synchronize(self):
         self._check(_lib.glf_ctx_synchronize(self._ctx))
+
+    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "NYS_NO_LUT", "NO_ECR", "GS", "RESIDUAL", "VERBOSE")
+
+    def set_tuning(self, **kw):
+        """glf_ctx_set_tuning: e.g. set_tuning(NYS_PATH="grid", MV_PATH="dense"); None / "" / "auto" = the default choice."""
+        for k, v in kw.items():
+            rc = _lib.glf_ctx_set_tuning(self._ctx, k.encode(), None if v is None else str(v).encode())
+            if rc != OK:
+                raise GlfError(rc, "set_tuning(%s=%r)" % (k, v))
+
+    def reset_tuning(self):
+        self.set_tuning(**{k: None for k in self.TUNING_KEYS})
 
     def debug_violations(self):
         """Guard zones of work buffers found overwritten (debug pool, GLF_POOL_DEBUG=1 at creation); -1 otherwise."""

@@ -7,7 +7,9 @@
  *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
  *                    [-dump_eigvecs] [-ngpu N [-ngpu_backend rccl|loopback]] [-filter_pow K]
- *                    [-kernel bilateral|photometric|spatial|nlm] [-h_loc X] [-h_val X] [-gain X]
+ *                    [-kernel bilateral|photometric|spatial|nlm] [-h_loc X] [-h_val X] [-gain X] [-dump_residual]
+ * -dump_residual writes results/residuals.png = |input - output| stretched to the full grey range, the PoC's residual image
+ * (python/image_processing.py:378-380: plt.imsave of np.abs(y - z) with cmap 'gray' autoscales min..max).
  * -no_approx runs the full-matrix mode (hpc/image_processing.c:155-181); -use_slepc is accepted and refused.
  * -ngpu N is the reference's `mpirun -n N` (hpc/image_processing.c:30-38, 45-76): ONE process, N GPUs, one context and
  * one host thread per device, pixel rows sharded, RCCL collectives over xGMI issued by the library (glf_multi_*).
@@ -383,6 +385,26 @@ int main(int argc, char **argv)
         if (write_png("results/output.png", output_img, (unsigned)width, (unsigned)height) != 0) status = status ? status : 4; /* :309 */
     } else if (!status) {
         status = 5;
+    }
+    if (output_img && opt_has("-dump_residual")) { /* residuals(y, z), python/image_processing.py:378-380 */
+        int lo = 255, hi = 0;
+        for (int r = 0; r < height; ++r)
+            for (int c = 0; c < width; ++c) {
+                const int d = abs((int)img_bytes[r][c] - (int)output_img[r][c]);
+                lo = d < lo ? d : lo;
+                hi = d > hi ? d : hi;
+            }
+        png_bytep *res = (png_bytep *)malloc(sizeof(png_bytep) * (size_t)height);
+        for (int r = 0; res && r < height; ++r) {
+            res[r] = (png_bytep)malloc((size_t)width);
+            for (int c = 0; res[r] && c < width; ++c) {
+                const int d = abs((int)img_bytes[r][c] - (int)output_img[r][c]);
+                res[r][c] = (png_byte)(hi > lo ? ((d - lo) * 255 + (hi - lo) / 2) / (hi - lo) : 0);
+            }
+        }
+        if (res && write_png("results/residuals.png", res, (unsigned)width, (unsigned)height) != 0) status = status ? status : 4;
+        free_rows(res, height);
+        printf("Residual |input - output|: min %d, max %d grey levels\n", lo, hi);
     }
     printf("Total computation time: %fs\n", wtime() - start_time); /* :314 */
 

@@ -213,7 +213,7 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
         got = {}
         for mode in ("grid_f16s", "direct_f16s", "direct_f32"):
             ctx.set_contraction(glf.CONTRACT_F32_MFMA if mode == "direct_f32" else glf.CONTRACT_F16_SPLIT)
-            monkeypatch.setenv("GLF_NYS_PATH", "grid" if mode == "grid_f16s" else "direct")
+            ctx.set_tuning(NYS_PATH="grid" if mode == "grid_f16s" else "direct")
             phi_sf = ctx.Nystroem(L_B, vecs, Pi_inv)
             phi = ctx.Permutation(phi_sf, idx)
             ctx.destroy(phi_sf)
@@ -225,7 +225,7 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
             got[mode] = (pt[rows].clone(), res)
             del pt
             ctx.destroy(phi)
-        monkeypatch.delenv("GLF_NYS_PATH", raising=False)
+        ctx.set_tuning(NYS_PATH=None)
         ctx.set_contraction(glf.CONTRACT_F16_SPLIT)
         key = "%dx%d h_loc=%g h_val=%g" % (size, size, h_loc, h_val)
         report[key] = {mode: got[mode][1] for mode in got}

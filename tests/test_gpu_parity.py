@@ -49,6 +49,15 @@ def ctx(request):
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_kernel_selection(request):
+    """Tests force kernel families through glf_ctx_set_tuning on the module-scoped context; every test starts and ends with
+    the default (size-based) selection."""
+    yield
+    if "ctx" in request.fixturenames:
+        request.getfixturevalue("ctx").reset_tuning()
+
+
 def _lapack_pairs(LA, m):
     w, V = np.linalg.eigh(LA)
     return np.ascontiguousarray(V[:, :m].T), w[:m]
@@ -89,7 +98,7 @@ def test_affinity_degree_laplacian(ctx, golden, png, name):
 @pytest.mark.parametrize("paths", ["direct", "grid"])
 @pytest.mark.parametrize("kernel,ok", [(glf.KERNEL_PHOTOMETRIC, orc.PHOTOMETRIC), (glf.KERNEL_SPATIAL, orc.SPATIAL)])
 def test_other_kernels_against_golden(ctx, golden, kernel, ok, paths, monkeypatch):
-    monkeypatch.setenv("GLF_DEG_PATH", paths)   # the degree in both forms (one factor of the kernel is constant here)
+    ctx.set_tuning(DEG_PATH=paths)   # the degree in both forms (one factor of the kernel is constant here)
     g = golden("syn32.npz")
     name = "photometric" if kernel == glf.KERNEL_PHOTOMETRIC else "spatial"
     d_img = ctx.to_device(g["img"])
@@ -237,17 +246,14 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
     phi_A, Pi = ctx.dense_from_numpy(vecs.T), ctx.diag_from_numpy(vals)
     Pi_inv = ctx.InverseDiagMat(Pi)
     got = {}
-    for mode, env in (("grid", {"GLF_NYS_PATH": "grid"}), ("grid_v1", {"GLF_NYS_PATH": "grid", "GLF_ROWPASS": "v1"}),
-                      ("lut", {"GLF_NYS_PATH": "direct"}), ("exp", {"GLF_NYS_PATH": "direct", "GLF_NYS_NO_LUT": "1"})):
-        for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT", "GLF_ROWPASS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for mode, tune in (("grid", {"NYS_PATH": "grid"}), ("grid_v1", {"NYS_PATH": "grid", "ROWPASS": "v1"}),
+                       ("lut", {"NYS_PATH": "direct"}), ("exp", {"NYS_PATH": "direct", "NYS_NO_LUT": "1"})):
+        ctx.set_tuning(NYS_PATH=None, NYS_NO_LUT=None, ROWPASS=None)
+        ctx.set_tuning(**tune)
         phi = ctx.Nystroem(L_B, phi_A, Pi_inv)
         got[mode] = ctx.mat_to_numpy(phi)
         ctx.destroy(phi)
-    for k in ("GLF_NYS_PATH", "GLF_NYS_NO_LUT", "GLF_ROWPASS"):
-        monkeypatch.delenv(k, raising=False)
+    ctx.set_tuning(NYS_PATH=None, NYS_NO_LUT=None, ROWPASS=None)
     scale = np.abs(ref).max()
     for mode in got:
         np.testing.assert_allclose(got[mode], ref, rtol=0, atol=PHI_TOL * scale, err_msg=mode)
@@ -267,11 +273,11 @@ def test_degree_paths_agree(ctx, w, h, ns, monkeypatch):
     d_img = ctx.to_device(img)
     got = {}
     for mode in ("grid", "direct"):
-        monkeypatch.setenv("GLF_DEG_PATH", mode)
+        ctx.set_tuning(DEG_PATH=mode)
         _, K_B = ctx.ComputeAffinityMatrices(d_img, idx, want_KA=False)
         got[mode] = ctx.degree_of(K_B)
         ctx.destroy(K_B)
-    monkeypatch.delenv("GLF_DEG_PATH", raising=False)
+    ctx.set_tuning(DEG_PATH=None)
     for mode in got:
         np.testing.assert_allclose(got[mode], ref, rtol=2e-6, err_msg=mode)
     np.testing.assert_allclose(got["grid"], got["direct"], rtol=5e-7)
@@ -417,12 +423,12 @@ def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, r
     """The grid-factored degree and Nystroem contraction are chosen automatically from 1024-pixel-wide images on;
     forced here on the small reference images (odd widths, m up to p - 1) against the fp64 oracle. rowpass: the default
     choice (row-tile kernel for the Nystroem passes, k_grid_rowpass for the L_A sweeps), or one kernel for both uses."""
-    monkeypatch.setenv("GLF_NYS_PATH", "grid")
-    monkeypatch.setenv("GLF_DEG_PATH", "grid")
-    monkeypatch.setenv("GLF_MV_PATH", "grid")
+    ctx.set_tuning(NYS_PATH="grid")
+    ctx.set_tuning(DEG_PATH="grid")
+    ctx.set_tuning(MV_PATH="grid")
     if rowpass != "default":
-        monkeypatch.setenv("GLF_ROWPASS", rowpass)
-        monkeypatch.setenv("GLF_ROWPASS_OP", rowpass)
+        ctx.set_tuning(ROWPASS=rowpass)
+        ctx.set_tuning(ROWPASS_OP=rowpass)
     img, _ = _images(golden, png)[name]
     out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
                                          want_float=True)
@@ -436,9 +442,8 @@ def test_end_to_end_with_grid_forms_forced(ctx, golden, png, name, ns, m, eps, r
 def test_end_to_end_other_kernels(ctx, kernel, ok, paths, monkeypatch):
     """Photometric-only and spatial-only kernels (hpc/affinity.c:8-57) through the whole path in both kernel families:
     one of the three factors of the grid forms is identically 1, and nothing underflows to zero for the photometric one."""
-    for k in ("GLF_NYS_PATH", "GLF_DEG_PATH"):
-        monkeypatch.setenv(k, paths)
-    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    ctx.set_tuning(NYS_PATH=paths, DEG_PATH=paths)
+    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
     img = glf.synth_image(128, 96, seed=13)
     prm = orc.default_params(ok)
     prm.h_loc, prm.h_val = 25.0, 35.0
@@ -551,9 +556,9 @@ def test_exact_zero_skipping_is_bit_identical(ctx, paths, monkeypatch):
     """glf_options.skip_exact_zeros drops whole 64-sample chunks whose kernel entries are exactly zero
     in the arithmetic in use; the result must not change by a single bit, only the executed work."""
     import torch
-    monkeypatch.setenv("GLF_NYS_PATH", paths)   # the grid-factored forms or the entry-by-entry kernels
-    monkeypatch.setenv("GLF_DEG_PATH", paths)
-    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    ctx.set_tuning(NYS_PATH=paths)   # the grid-factored forms or the entry-by-entry kernels
+    ctx.set_tuning(DEG_PATH=paths)
+    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
     img = glf.synth_image(1280, 1024, seed=11)
     d_img = ctx.to_device(img)
     ns = int(1280 * 1024 * 0.005)
@@ -597,9 +602,9 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     """Tiny images (p < one 64-sample chunk) and the widest supported blocks (ld = 128, 256: the MB = 4 / 8
     instantiations of the direct kernel, two / four 64-column blocks of the grid form) against the oracle.
     m = 256 is the stated upper limit of this build."""
-    monkeypatch.setenv("GLF_NYS_PATH", paths)
-    monkeypatch.setenv("GLF_DEG_PATH", paths)
-    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    ctx.set_tuning(NYS_PATH=paths)
+    ctx.set_tuning(DEG_PATH=paths)
+    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
     img = glf.synth_image(w, h, seed=21)
     eps = 0.2
     opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
@@ -671,9 +676,9 @@ def test_more_than_256_eigenpairs_end_to_end(ctx, ns, m, paths, monkeypatch):
     """The reference's default is m = p - 1 eigenpairs (hpc/image_processing.c:96-108; num_eigvals = 0 here): beyond 256 the
     vectors are processed as panels of 256 columns (cross-panel terms of the classical Gram-Schmidt and of the residual as small
     f64 GEMMs). 256 x 192 image: p = 588 -> m = 587 = panels of 256 + 256 + 75; m = 300 and m = 257 (a one-column last panel)."""
-    monkeypatch.setenv("GLF_NYS_PATH", paths)
-    monkeypatch.setenv("GLF_DEG_PATH", paths)
-    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    ctx.set_tuning(NYS_PATH=paths)
+    ctx.set_tuning(DEG_PATH=paths)
+    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
     img = glf.synth_image(256, 192, seed=17)
     eps = 0.2
     p = glf.Sampling(256, 192, ns).size
@@ -742,9 +747,9 @@ def test_grid_forms_with_many_grid_rows_or_columns(ctx, w, h, ns, monkeypatch):
     d_img = ctx.to_device(img)
     res = {}
     for paths in ("grid", "direct"):
-        monkeypatch.setenv("GLF_NYS_PATH", paths)
-        monkeypatch.setenv("GLF_DEG_PATH", paths)
-        monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+        ctx.set_tuning(NYS_PATH=paths)
+        ctx.set_tuning(DEG_PATH=paths)
+        ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
         for skip in (0, 1):
             opt = glf.default_options(num_samples=ns, num_eigvals=24, epsilon=0.2, skip_exact_zeros=skip)
             out, zf, info = ctx.image_processing(d_img, opt, want_float=True)

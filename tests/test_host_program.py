@@ -190,3 +190,18 @@ def test_kernel_flag_nlm(tmp_path, png):
         assert psnr(glf.read_png(os.path.join(d, "results", "output.png")), out_ref) >= 50.0
     bad = _run(["-f", TEST_PNG, "-kernel", "gabor"], str(tmp_path))
     assert bad.returncode == 1 and b"expected bilateral, photometric, spatial or nlm" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_residual_image(tmp_path, png):
+    """-dump_residual: the PoC's residual image |y - z| (python/image_processing.py:378-380), stretched min..max."""
+    r = _run(["-f", TEST_PNG, "-num_eigvals", "16", "-gain", "60", "-dump_residual"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()
+    img = png("test.png").astype(int)
+    out = glf.read_png(str(tmp_path / "results" / "output.png")).astype(int)
+    res = glf.read_png(str(tmp_path / "results" / "residuals.png")).astype(int)
+    d = np.abs(img - out)
+    assert d.max() > d.min()
+    expect = ((d - d.min()) * 255 + (d.max() - d.min()) // 2) // (d.max() - d.min())
+    np.testing.assert_array_equal(res, expect)
+    assert ("Residual |input - output|: min %d, max %d grey levels" % (d.min(), d.max())) in r.stdout.decode()
