@@ -227,7 +227,7 @@ template <int NW = 4>
 __device__ __forceinline__ void lds_dma_copy(const void *gsrc, void *ldst, int pieces, int wave, int lane)
 {
     const char *g = reinterpret_cast<const char *>(gsrc);
-    const unsigned base = lds_offset_of(ldst);
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset_of(ldst)); // (wave-uniform: goes to m0)
     const int uw = __builtin_amdgcn_readfirstlane(wave);
     for (int i = uw; i < pieces; i += NW) lds_dma_16B(g + (size_t)i * 1024 + lane * 16, base + (unsigned)i * 1024u);
 }

@@ -32,7 +32,7 @@ def _check(img, opt, n, backend, devices):
         np.testing.assert_allclose(i["eigvals"], info1["eigvals"], rtol=1e-5)
         np.testing.assert_array_equal(i["eigvals"], infos[0]["eigvals"])            # all-reduced sums: identical on every rank
         assert i["alpha"] == infos[0]["alpha"]
-    assert infos[0]["alpha"] == pytest.approx(info1["alpha"], rel=1e-12)
+    assert infos[0]["alpha"] == pytest.approx(info1["alpha"], rel=1e-7)     # (the grid degree sums f32 chunks of 512 image rows: a shard moves the chunk boundaries)
     np.testing.assert_allclose(zf, zf1, rtol=0, atol=5e-4)
     assert np.mean(out != out1) < 1e-3 and psnr(out, out1) >= 60.0
     np.testing.assert_array_equal(zf_b.view(np.int32), zf.view(np.int32))          # run-to-run reproducible
