@@ -304,6 +304,7 @@ void glf_options_default(glf_options *opt)
     opt->h_val = 30.0f;        // hpc/affinity.c:117
     opt->kernel = GLF_KERNEL_BILATERAL;
     opt->filter_pow = 1;       // MatPow no-op, hpc/utils.c:721
+    opt->filter_mode = GLF_FILTER_REFERENCE;
     opt->skip_exact_zeros = 0; // evaluate every entry, as the reference does
 }
 

@@ -469,6 +469,14 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         opt = *opt_in;
     }
     if (opt.kernel < GLF_KERNEL_BILATERAL || opt.kernel > GLF_KERNEL_NLM) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", opt.kernel);
+    if (opt.filter_mode != GLF_FILTER_REFERENCE && opt.filter_mode != GLF_FILTER_POC) return set_error(ctx, GLF_ERR_INVALID, "filter_mode %d", opt.filter_mode);
+    // f(Pi) and the gain of the filter: the reference's z = y + gain Phi Pi^k Phi^T y (MatPow is a no-op there, hpc/utils.c:721 => k = 1),
+    // or the PoC's z = y - Phi diag(mu + 5) Phi^T y (python/image_processing.py:304-305)
+    const bool poc_filter = opt.filter_mode == GLF_FILTER_POC;
+    const float filter_gain = poc_filter ? 1.0f : opt.gain;
+    auto filter_weight = [&](double lambda) {
+        return poc_filter ? -(lambda + 5.0) : std::pow(lambda, (double)(opt.filter_pow > 0 ? opt.filter_pow : 1));
+    };
     const int64_t N = (int64_t)width * height;
     if (N >= (int64_t)1 << 31) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too large");
     hipStream_t st = ctx->stream;
@@ -643,13 +651,13 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
             GLF_HIP(ctx, hipStreamSynchronize(st));
             std::vector<float> hw(PANEL_COLS, 0.f);
             for (unsigned j = 0; j < mq; ++j)
-                hw[j] = (float)(std::pow(lamw[q * PANEL_COLS + j], (double)(opt.filter_pow > 0 ? opt.filter_pow : 1)) * hc[j]);
+                hw[j] = (float)(filter_weight(lamw[q * PANEL_COLS + j]) * hc[j]);
             GLF_HIP(ctx, hipMemcpyAsync(ww.p, hw.data(), sizeof(float) * PANEL_COLS, hipMemcpyHostToDevice, st));
             GLF_HIP(ctx, hipStreamSynchronize(st));
             GLF_TRY(filter_accumulate(ctx, phiw.p, pix0, pix1, PANEL_COLS, ww.p, acc.p, q == 0));
         }
         GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        GLF_TRY(filter_finish(ctx, d_img, acc.p, pix0, pix1, opt.gain, d_out, d_zf));
+        GLF_TRY(filter_finish(ctx, d_img, acc.p, pix0, pix1, filter_gain, d_out, d_zf));
         GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
         GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
         S.nystroem_launches = (int)npan;
@@ -735,12 +743,11 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         GLF_HIP(ctx, hipStreamSynchronize(st));
         if (cap && cap->h_c) std::memcpy(cap->h_c, hc.data(), sizeof(double) * ld);
         std::vector<float> hw(ld, 0.f);
-        // f(Pi): MatPow(eigvals, 6) is a no-op in the reference (hpc/utils.c:721) => filter_pow = 1
-        for (unsigned j = 0; j < m; ++j) hw[j] = (float)(std::pow(lam[j], (double)(opt.filter_pow > 0 ? opt.filter_pow : 1)) * hc[j]);
+        for (unsigned j = 0; j < m; ++j) hw[j] = (float)(filter_weight(lam[j]) * hc[j]);
         GLF_HIP(ctx, hipMemcpyAsync(w.p, hw.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }
-    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, opt.gain, d_out, d_zf, cap ? cap->d_corr : nullptr));
+    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, filter_gain, d_out, d_zf, cap ? cap->d_corr : nullptr));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
     GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
     GLF_HIP(ctx, hipEventElapsedTime(&S.ms_affinity, ctx->ev[0], ctx->ev[1]));

@@ -34,6 +34,7 @@ MAT_DENSE, MAT_DIAG, MAT_KERNEL_B = 0, 1, 2
 ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
 KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL, KERNEL_NLM = 0, 1, 2, 3
 CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
+FILTER_REFERENCE, FILTER_POC = 0, 1
 MULTI_RCCL, MULTI_LOOPBACK = 0, 1
 RCCL_ID_BYTES = 128
 
@@ -46,7 +47,7 @@ EXPORTS = [
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
     "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
-    "glf_options_default", "glf_image_processing", "glf_image_processing_capture", "glf_ctx_debug_violations", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png",
+    "glf_options_default", "glf_image_processing", "glf_image_processing_capture", "glf_ctx_debug_violations", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png", "glf_read_png_rgb", "glf_write_png_rgb",
 ]
 
 
@@ -72,7 +73,7 @@ class Options(C.Structure):
         ("num_eigvals", C.c_uint32), ("opti_gs", C.c_int32), ("epsilon", C.c_double),
         ("inner_rtol", C.c_double), ("max_outer", C.c_int32), ("seed", C.c_uint64), ("gain", C.c_float),
         ("h_loc", C.c_float), ("h_val", C.c_float), ("kernel", C.c_int32), ("filter_pow", C.c_int32),
-        ("skip_exact_zeros", C.c_int32),
+        ("filter_mode", C.c_int32), ("skip_exact_zeros", C.c_int32),
     ]
 
 
@@ -171,6 +172,20 @@ def read_png(path):
     img = np.empty((h.value, w.value), dtype=np.uint8)
     for r in range(h.value):
         img[r] = np.ctypeslib.as_array(rows[r], shape=(w.value,))
+        _lib.glf_host_free(rows[r])
+    _lib.glf_host_free(rows)
+    return img
+
+
+def read_png_rgb(path):
+    rows = C.POINTER(C.POINTER(C.c_uint8))()
+    w, h = C.c_int(), C.c_int()
+    rc = _lib.glf_read_png_rgb(path.encode(), C.byref(rows), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise GlfError(ERR_IO, path)
+    img = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    for r in range(h.value):
+        img[r] = np.ctypeslib.as_array(rows[r], shape=(w.value * 3,)).reshape(w.value, 3)
         _lib.glf_host_free(rows[r])
     _lib.glf_host_free(rows)
     return img

@@ -8,6 +8,11 @@
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
  *                    [-dump_eigvecs] [-ngpu N [-ngpu_backend rccl|loopback]] [-filter_pow K]
  *                    [-kernel bilateral|photometric|spatial|nlm] [-h_loc X] [-h_val X] [-gain X] [-dump_residual]
+ *                    [-filter reference|poc] [-color]
+ * -filter poc applies the Python PoC's active filter z = y - Phi diag(mu + 5) Phi^T y (python/image_processing.py:304-305) instead
+ * of hpc/display.c:58-83. -color keeps the colours of an RGB(A) input the way the PoC does (python/image_processing.py:410-432):
+ * RGB -> YUV (python/utils.py:33-44), the luma plane is filtered, the chroma planes pass through, YUV -> RGB; the luma is
+ * rounded to 8 bits first because every kernel here works on u8 pixel values (the PoC filters the unrounded floats).
  * -dump_residual writes results/residuals.png = |input - output| stretched to the full grey range, the PoC's residual image
  * (python/image_processing.py:378-380: plt.imsave of np.abs(y - z) with cmap 'gray' autoscales min..max).
  * -no_approx runs the full-matrix mode (hpc/image_processing.c:155-181); -use_slepc is accepted and refused.
@@ -230,6 +235,7 @@ static void fill_options(glf_options *opt, unsigned width, unsigned height)
     opt->h_val = stage_h_val;
     opt->gain = stage_gain;
     if ((v = opt_value("-filter_pow")) && atoi(v) > 0) opt->filter_pow = atoi(v);
+    if ((v = opt_value("-filter")) && strcmp(v, "poc") == 0) opt->filter_mode = GLF_FILTER_POC;
 }
 
 static void print_stage_times(const glf_stats *st, double epsilon)
@@ -285,6 +291,84 @@ out:
     free(flat_out);
     free(st);
     glf_multi_destroy(world);
+    return rows;
+}
+
+/* -color (python/image_processing.py:410-432): filter the luma of an RGB image, keep its chroma. Returns rows of 3 * width
+ * bytes for glf_write_png_rgb; *input_rgb receives the input as read (for results/input.png). */
+static const double yuv_from_rgb[3][3] = {{0.299, 0.587, 0.114},                 /* python/utils.py:33-36 (the BT.601 YUV matrix) */
+                                          {-0.14714119, -0.28886916, 0.43601035},
+                                          {0.61497538, -0.51496512, -0.10001026}};
+static png_bytep *ColorComputation(const char *filename, unsigned *width_out, unsigned *height_out, png_bytep **input_rgb)
+{
+    int w = 0, h = 0;
+    png_bytep *rgb = NULL, *rows = NULL;
+    if (glf_read_png_rgb(filename, &rgb, &w, &h) != 0) return NULL;
+    *width_out = (unsigned)w;
+    *height_out = (unsigned)h;
+    *input_rgb = rgb;
+    printf("Read image %s of size %dx%d => %d pixels (colour: the luma plane is filtered)\n", filename, w, h, w * h);
+    const size_t n = (size_t)w * h;
+    /* rgb_from_yuv = inv(yuv_from_rgb), python/utils.py:38 */
+    double inv[3][3];
+    {
+        const double(*a)[3] = yuv_from_rgb;
+        const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const int r0 = (j + 1) % 3, r1 = (j + 2) % 3, c0 = (i + 1) % 3, c1 = (i + 2) % 3;
+                inv[i][j] = (a[r0][c0] * a[r1][c1] - a[r0][c1] * a[r1][c0]) / det;
+            }
+    }
+    double *yuv = (double *)malloc(sizeof(double) * 3 * n);
+    uint8_t *luma = (uint8_t *)malloc(n);
+    float *zf = (float *)malloc(sizeof(float) * n);
+    glf_ctx *ctx = glf_world();
+    void *d_img = NULL, *d_out = NULL, *d_zf = NULL;
+    if (!yuv || !luma || !zf) goto out;
+    for (int r = 0; r < h; ++r)
+        for (int c = 0; c < w; ++c) {
+            const double R = rgb[r][3 * c], G = rgb[r][3 * c + 1], B = rgb[r][3 * c + 2];
+            const size_t i = (size_t)r * w + c;
+            for (int k = 0; k < 3; ++k) yuv[k * n + i] = R * yuv_from_rgb[k][0] + G * yuv_from_rgb[k][1] + B * yuv_from_rgb[k][2]; /* rgb2ycc */
+            double y = yuv[i] + 0.5;
+            luma[i] = (uint8_t)(y < 0.0 ? 0.0 : (y > 255.0 ? 255.0 : y));
+        }
+    if (glf_malloc(ctx, &d_img, n) != GLF_OK || glf_malloc(ctx, &d_out, n) != GLF_OK || glf_malloc(ctx, &d_zf, sizeof(float) * n) != GLF_OK) goto out;
+    if (glf_memcpy_h2d(ctx, d_img, luma, n) != GLF_OK) goto out;
+    glf_options opt;
+    fill_options(&opt, (unsigned)w, (unsigned)h);
+    glf_stats st;
+    {
+        const int rc = glf_image_processing(ctx, &opt, (const uint8_t *)d_img, w, h, (uint8_t *)d_out, (float *)d_zf, NULL, &st);
+        if (rc != GLF_OK) {
+            fprintf(stderr, "glf_image_processing: %s (%s)\n", glf_strerror(rc), glf_ctx_last_error(ctx));
+            goto out;
+        }
+    }
+    print_stage_times(&st, opt.epsilon);
+    if (glf_memcpy_d2h(ctx, zf, d_zf, sizeof(float) * n) != GLF_OK) goto out;
+    rows = (png_bytep *)malloc(sizeof(png_bytep) * (size_t)h);
+    for (int r = 0; rows && r < h; ++r) {
+        rows[r] = (png_bytep)malloc(3 * (size_t)w);
+        for (int c = 0; rows[r] && c < w; ++c) {
+            const size_t i = (size_t)r * w + c;
+            const double zy = (double)zf[i], u = yuv[n + i], v = yuv[2 * n + i]; /* z[:, :, 0] = z_ycc; chroma unchanged */
+            for (int k = 0; k < 3; ++k) {                                          /* ycc2rgb, then astype(uint8) made safe */
+                double x = zy * inv[k][0] + u * inv[k][1] + v * inv[k][2];
+                x = x < 0.0 ? 0.0 : (x > 255.0 ? 255.0 : x);
+                rows[r][3 * c + k] = (png_byte)x;
+            }
+        }
+    }
+out:
+    free(yuv);
+    free(luma);
+    free(zf);
+    if (d_img) glf_free(ctx, d_img);
+    if (d_out) glf_free(ctx, d_out);
+    if (d_zf) glf_free(ctx, d_zf);
     return rows;
 }
 
@@ -361,6 +445,23 @@ int main(int argc, char **argv)
 
     int width = 0, height = 0;
     png_bytep *img_bytes = NULL, *output_img = NULL;
+    if (opt_has("-color")) { /* python/image_processing.py:410-432 */
+        unsigned cw = 0, ch = 0;
+        png_bytep *in_rgb = NULL;
+        png_bytep *out_rgb = ColorComputation(filename, &cw, &ch, &in_rgb);
+        int cstatus = out_rgb ? 0 : 5;
+        if (in_rgb && glf_write_png_rgb("results/input.png", in_rgb, cw, ch) != 0) cstatus = cstatus ? cstatus : 4;
+        if (out_rgb && glf_write_png_rgb("results/output.png", out_rgb, cw, ch) != 0) cstatus = cstatus ? cstatus : 4;
+        if (!in_rgb) {
+            fprintf(stderr, "Could not read %s as an 8-bit gray / RGB / RGBA PNG\n", filename);
+            cstatus = 1;
+        }
+        printf("Total computation time: %fs\n", wtime() - start_time);
+        free_rows(in_rgb, (int)ch);
+        free_rows(out_rgb, (int)ch);
+        FinalizeProgram();
+        return cstatus;
+    }
     if (read_png(filename, &img_bytes, &width, &height) != 0) { /* ReadAndBcastImage :291; status checked here */
         fprintf(stderr, "Could not read %s as an 8-bit gray / RGB / RGBA PNG\n", filename);
         FinalizeProgram();

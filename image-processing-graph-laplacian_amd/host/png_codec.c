@@ -38,7 +38,8 @@ static int paeth(int a, int b, int c)
     return (pb <= pc) ? b : c;
 }
 
-int glf_read_png(const char *filename, uint8_t ***row_pointers, int *width, int *height)
+/* want_rgb: rows of 3 * width bytes (R, G, B interleaved; a gray file replicates its value) instead of the gray conversion */
+static int read_png_impl(const char *filename, uint8_t ***row_pointers, int *width, int *height, int want_rgb)
 {
     if (!filename || !row_pointers || !width || !height) return -1;
     *row_pointers = NULL;
@@ -150,10 +151,13 @@ int glf_read_png(const char *filename, uint8_t ***row_pointers, int *width, int 
     rows = (uint8_t **)calloc(h, sizeof(uint8_t *));
     if (!rows) goto done;
     for (uint32_t y = 0; y < h; ++y) {
-        rows[y] = (uint8_t *)malloc(w);
+        rows[y] = (uint8_t *)malloc(want_rgb ? 3 * (size_t)w : w);
         if (!rows[y]) goto done;
         const uint8_t *src = raw + (stride + 1) * y + 1;
-        if (channels == 1) memcpy(rows[y], src, w);
+        if (want_rgb) {
+            for (uint32_t x = 0; x < w; ++x)
+                for (int ch = 0; ch < 3; ++ch) rows[y][3 * x + ch] = channels == 1 ? src[x] : src[x * channels + ch];
+        } else if (channels == 1) memcpy(rows[y], src, w);
         else
             for (uint32_t x = 0; x < w; ++x) {
                 const uint32_t r = src[x * channels], g = src[x * channels + 1], b = src[x * channels + 2];
@@ -182,6 +186,16 @@ done:
     return rc;
 }
 
+int glf_read_png(const char *filename, uint8_t ***row_pointers, int *width, int *height)
+{
+    return read_png_impl(filename, row_pointers, width, height, 0);
+}
+
+int glf_read_png_rgb(const char *filename, uint8_t ***row_pointers, int *width, int *height)
+{
+    return read_png_impl(filename, row_pointers, width, height, 1);
+}
+
 static int write_chunk(FILE *f, const char *type, const uint8_t *data, uint32_t len)
 {
     uint8_t hdr[8], crcb[4];
@@ -196,7 +210,19 @@ static int write_chunk(FILE *f, const char *type, const uint8_t *data, uint32_t 
     return 0;
 }
 
+static int write_png_impl(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height, int rgb);
+
 int glf_write_png(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height)
+{
+    return write_png_impl(filename, img_bytes, width, height, 0);
+}
+
+int glf_write_png_rgb(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height)
+{
+    return write_png_impl(filename, img_bytes, width, height, 1);
+}
+
+static int write_png_impl(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height, int rgb)
 {
     if (!filename || !img_bytes || width == 0 || height == 0) return -1;
     FILE *f = fopen(filename, "wb");
@@ -205,21 +231,22 @@ int glf_write_png(const char *filename, uint8_t **img_bytes, unsigned width, uns
         return -1;
     }
     int rc = -1;
-    const size_t rawlen = ((size_t)width + 1) * height;
+    const size_t rowbytes = (size_t)width * (rgb ? 3 : 1);
+    const size_t rawlen = (rowbytes + 1) * height;
     uint8_t *raw = (uint8_t *)malloc(rawlen), *z = NULL;
     uLongf zlen = compressBound((uLong)rawlen);
     uint8_t ihdr[13];
     if (!raw) goto done;
     for (unsigned y = 0; y < height; ++y) {
-        raw[((size_t)width + 1) * y] = 0; /* filter type None */
-        memcpy(raw + ((size_t)width + 1) * y + 1, img_bytes[y], width);
+        raw[(rowbytes + 1) * y] = 0; /* filter type None */
+        memcpy(raw + (rowbytes + 1) * y + 1, img_bytes[y], rowbytes);
     }
     z = (uint8_t *)malloc(zlen);
     if (!z || compress2(z, &zlen, raw, (uLong)rawlen, 6) != Z_OK) goto done;
     put_be32(ihdr, width);
     put_be32(ihdr + 4, height);
     ihdr[8] = 8;  /* bit depth,  hpc/write_img.c:39 */
-    ihdr[9] = 0;  /* PNG_COLOR_TYPE_GRAY, :38 */
+    ihdr[9] = rgb ? 2 : 0; /* PNG_COLOR_TYPE_GRAY, :38 (2 = RGB for the colour path) */
     ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0; /* base compression/filter, no interlace, :42-44 */
     if (fwrite(PNG_SIG, 1, 8, f) != 8) goto done;
     if (write_chunk(f, "IHDR", ihdr, 13) != 0) goto done;

@@ -263,6 +263,7 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
 
 /* ---- whole path ----------------------------------------------------------------- */
 
+enum { GLF_FILTER_REFERENCE = 0, GLF_FILTER_POC = 1 };
 typedef struct glf_options {
     uint32_t struct_size;   /* sizeof(glf_options) */
     uint32_t num_samples;   /* requested sample count; 0 -> width*height*sample_frac (hpc/image_processing.c:187) */
@@ -277,6 +278,9 @@ typedef struct glf_options {
     float h_loc, h_val;     /* 40, 30 hpc/affinity.c:117-118 */
     int32_t kernel;         /* GLF_KERNEL_BILATERAL */
     int32_t filter_pow;     /* 1: f(Pi) = Pi (MatPow is a no-op, hpc/utils.c:721); k: Pi^k */
+    int32_t filter_mode;    /* GLF_FILTER_REFERENCE (0): z = y + gain Phi Pi^filter_pow Phi^T y, clamp, cast (hpc/display.c:58-83);
+                               GLF_FILTER_POC (1): the Python PoC's active filter z = y - Phi diag(mu + 5) Phi^T y
+                               (python/image_processing.py:304-305; gain and filter_pow ignored), same clamp and cast */
     int32_t skip_exact_zeros; /* 0 (default): every K_B / K_A entry is evaluated, as the reference does.
                                  1: entries that are exactly zero in the arithmetic in use (pixel-sample
                                  distance beyond the radius where exp underflows) are skipped in whole tiles;
@@ -370,6 +374,10 @@ int glf_EntireComputation(glf_ctx *ctx, const uint8_t *d_img, int width, int hei
 int glf_read_png(const char *filename, uint8_t ***row_pointers, int *width, int *height);
 /* int write_png(const char*, png_bytep* rows, unsigned w, unsigned h)  hpc/write_img.h:4, hpc/write_img.c:5-53 */
 int glf_write_png(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height);
+/* Colour (python/image_processing.py:410-432: the PoC filters the luma of an RGB image and keeps the chroma; the C reference
+ * converts to gray on read): the same codec with rows of 3 * width bytes, R G B interleaved. */
+int glf_read_png_rgb(const char *filename, uint8_t ***row_pointers, int *width, int *height);
+int glf_write_png_rgb(const char *filename, uint8_t **img_bytes, unsigned width, unsigned height);
 
 #ifdef __cplusplus
 }

@@ -138,3 +138,26 @@ def test_context_needs_a_gpu_and_fails_loudly():
     ctx = C.c_void_p()
     rc = glf._lib.glf_ctx_create(C.byref(ctx), 0, None)
     assert rc == glf.ERR_NODEVICE and not ctx.value
+
+
+def test_png_rgb_codec(tmp_path):
+    """The colour variant of the codec (rows of 3 * width bytes): the reference's RGB fixture against Pillow, a gray file
+    replicated into the three channels, and a write / read round trip."""
+    from PIL import Image
+    src = os.path.join(ROOT, "tests", "golden", "pixel_mountains.png")
+    rgb = glf.read_png_rgb(src)
+    np.testing.assert_array_equal(rgb, np.array(Image.open(src).convert("RGB")))
+    gray = glf.read_png_rgb(os.path.join(ROOT, "tests", "golden", "test.png"))
+    ref = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "test.png")))
+    for ch in range(3):
+        np.testing.assert_array_equal(gray[:, :, ch], ref)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    rows = (C.POINTER(C.c_uint8) * 37)()
+    flat = np.ascontiguousarray(img)
+    for r in range(37):
+        rows[r] = C.cast(flat.ctypes.data + r * 53 * 3, C.POINTER(C.c_uint8))
+    path = str(tmp_path / "rgb.png")
+    assert glf._lib.glf_write_png_rgb(path.encode(), rows, C.c_uint(53), C.c_uint(37)) == 0
+    np.testing.assert_array_equal(glf.read_png_rgb(path), img)
+    np.testing.assert_array_equal(np.array(Image.open(path)), img)

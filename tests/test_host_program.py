@@ -205,3 +205,40 @@ def test_residual_image(tmp_path, png):
     expect = ((d - d.min()) * 255 + (d.max() - d.min()) // 2) // (d.max() - d.min())
     np.testing.assert_array_equal(res, expect)
     assert ("Residual |input - output|: min %d, max %d grey levels" % (d.min(), d.max())) in r.stdout.decode()
+
+
+YUV_FROM_RGB = np.array([[0.299, 0.587, 0.114], [-0.14714119, -0.28886916, 0.43601035], [0.61497538, -0.51496512, -0.10001026]])
+
+
+@pytest.mark.gpu
+def test_color_and_poc_filter(tmp_path):
+    """-color: the PoC's colour handling (python/image_processing.py:410-432): RGB -> YUV, the luma is filtered, the chroma
+    kept, YUV -> RGB; -filter poc: its active filter z = y - Phi diag(mu + 5) Phi^T y (:304-305). Emulated here with the oracle's
+    stages on the 8-bit luma."""
+    src = os.path.join(ROOT, "tests", "golden", "pixel_mountains.png")
+    rgb = glf.read_png_rgb(src).astype(np.float64)
+    h, w, _ = rgb.shape
+    yuv = rgb @ YUV_FROM_RGB.T
+    luma = np.clip(np.floor(yuv[:, :, 0] + 0.5), 0, 255).astype(np.uint8)
+    ns, m = 300, 16
+    for flt in ("reference", "poc"):
+        d = str(tmp_path / flt)
+        r = _run(["-f", src, "-color", "-num_samples", str(ns), "-num_eigvals", str(m), "-filter", flt], d)
+        assert r.returncode == 0, r.stderr.decode()
+        assert "colour: the luma plane is filtered" in r.stdout.decode()
+        out = glf.read_png_rgb(os.path.join(d, "results", "output.png")).astype(np.float64)
+        np.testing.assert_array_equal(glf.read_png_rgb(os.path.join(d, "results", "input.png")), rgb.astype(np.uint8))
+        # oracle: the filter on the rounded luma, by stages
+        idx = orc.sampling(w, h, ns)
+        KA, _ = orc.affinity(luma, idx, want_KB=False)
+        LA, alpha = orc.laplacian(KA, orc.degree(luma, idx))
+        vecs, vals, _ = orc.inverse_power_iteration(LA, m, orc.random_vectors(idx.size, m, 1), epsilon=0.1, inner_rtol=1e-5)
+        phi = orc.permutation(orc.nystroem(luma, idx, alpha, vecs, vals), idx)
+        if flt == "reference":
+            zf, _ = orc.result_from_laplacian(luma, phi, vals, gain=3.0)
+        else:
+            zf, _ = orc.result_from_laplacian(luma, phi, -(vals + 5.0), gain=1.0)
+        z = np.stack([zf, yuv[:, :, 1], yuv[:, :, 2]], axis=2) @ np.linalg.inv(YUV_FROM_RGB).T
+        ref = np.clip(z, 0, 255).astype(np.uint8).astype(np.float64)
+        assert psnr(out, ref) >= 45.0, flt
+        assert np.mean(np.abs(out - ref) <= 1) >= 0.99
