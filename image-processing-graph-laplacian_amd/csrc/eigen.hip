@@ -785,8 +785,52 @@ __global__ void k_diag_inv(const float *__restrict__ A, int64_t lda, unsigned p,
     if (i < p) dinv[i] = 1.0f / A[(size_t)i * lda + i];
 }
 
+// Narrow sweeps: once most columns of a block have converged, the operator is applied to the active ones only, packed to
+// the left of a narrower block (the grid-factored operator costs in proportion to the block width, and the last step of
+// nearly every solve iterates on a single straggler). Columns are independent in the operator -- scales, split and sums
+// are per column -- so the packed application returns the same numbers.
+__device__ __forceinline__ int cg_active_map(const int *__restrict__ active, unsigned ld, int *map /* LDS [256] */, int *count /* LDS */)
+{
+    const int t = threadIdx.x;
+    if (t < (int)ld) {
+        int rank = 0;
+        for (int j = 0; j < t; ++j) rank += active[j] != 0;
+        if (active[t]) map[rank] = t;
+        if (t == (int)ld - 1) *count = rank + (active[t] != 0);
+    }
+    __syncthreads();
+    return *count;
+}
+
+__global__ __launch_bounds__(256) void k_cg_pack(const float *__restrict__ P, const int *__restrict__ active, unsigned p, unsigned ld,
+                                                  unsigned wn, float *__restrict__ Pc)
+{
+    __shared__ int map[256], count;
+    const int nact = cg_active_map(active, ld, map, &count);
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned e = threadIdx.x; e < RED_ROWS * wn; e += 256) {
+        const unsigned i = base + e / wn, r = e % wn;
+        if (i >= p) break;
+        Pc[(size_t)i * wn + r] = (int)r < nact ? P[(size_t)i * ld + map[r]] : 0.f;
+    }
+}
+
+// rows [r0, r0 + n) of the packed result back into the active columns of AP
+__global__ __launch_bounds__(256) void k_cg_unpack(const float *__restrict__ APc, const int *__restrict__ active, unsigned r0, unsigned n,
+                                                    unsigned ld, unsigned wn, float *__restrict__ AP)
+{
+    __shared__ int map[256], count;
+    const int nact = cg_active_map(active, ld, map, &count);
+    const unsigned base = blockIdx.x * RED_ROWS;
+    for (unsigned e = threadIdx.x; e < RED_ROWS * wn; e += 256) {
+        const unsigned il = base + e / wn, r = e % wn;
+        if (il >= n) break;
+        if ((int)r < nact) AP[(size_t)(r0 + il) * ld + map[r]] = APc[(size_t)(r0 + il) * wn + r];
+    }
+}
+
 struct CgWork {
-    DevBuf<float> R, P, AP, Xs, dinv;
+    DevBuf<float> R, P, AP, Xs, dinv, Pc, APc;
     DevBuf<double> partial, scal, sums;
     DevBuf<int> flags;
     CgScalars s{};
@@ -859,7 +903,28 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
     while (*(volatile int *)w.h_nactive > 0 && it < max_it) {
         ++it;
         if (rows.dist) GLF_TRY(allgather_rows(ctx, w.P.p, w.shard, ld)); // the operator needs every row of its operand
-        GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld, w.shard));
+        unsigned wn = ld; // block width of this sweep
+        if (w.shard && w.shard->grid && ld >= 64 && !ctx->tune.no_narrow) {
+            const int na = *w.h_nactive; // (as of the synchronise that ended the step before)
+            const unsigned cand = na <= 32 ? 32u : (unsigned)round_up(na, 64);
+            if (cand < ld) wn = cand;
+        }
+        if (wn < ld) {
+            if (!w.Pc.p) {
+                const size_t n = (size_t)vec_rows(p, w.shard, ctx->comm.size) * ld;
+                GLF_TRY(w.Pc.alloc(ctx, n));
+                GLF_TRY(w.APc.alloc(ctx, n));
+                GLF_HIP(ctx, hipMemsetAsync(w.Pc.p, 0, n * sizeof(float), st)); // (rows beyond p stay zero)
+            }
+            hipLaunchKernelGGL(k_cg_pack, dim3((unsigned)ceil_div(p, RED_ROWS)), dim3(256), 0, st, w.P.p, w.s.active, p, ld, wn, w.Pc.p);
+            GLF_TRY(block_matvec(ctx, A, lda, p, w.Pc.p, w.APc.p, wn, w.shard));
+            if (nblk > 0)
+                hipLaunchKernelGGL(k_cg_unpack, dim3(nblk), dim3(256), 0, st, w.APc.p, w.s.active, rows.r0, nloc, ld, wn, w.AP.p);
+            ++ctx->narrow_sweeps;
+            if (ctx->tune.verbose) fprintf(stderr, "[glf] block PCG step %d: operator applied to %u packed columns\n", it, wn);
+        } else {
+            GLF_TRY(block_matvec(ctx, A, lda, p, w.P.p, w.AP.p, ld, w.shard));
+        }
         if (nblk > 0) hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p + off, w.AP.p + off, nloc, ld, w.partial.p);
         GLF_TRY(reduce2(1, &src, &src_blk));
         hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, st, src, src_blk, ld, w.s);
@@ -872,6 +937,7 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
             hipLaunchKernelGGL(k_cg_pupdate, dim3(nelem_blocks), dim3(256), 0, st, w.P.p + off, w.R.p + off, w.dinv.p + rows.r0, nloc, ld, w.s);
         GLF_LAUNCH_CHECK(ctx);
         GLF_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->tune.verbose) fprintf(stderr, "[glf] block PCG step %d: %d of %u columns active\n", it, *w.h_nactive, m);
     }
     if (nloc > 0) GLF_HIP(ctx, hipMemcpyAsync(XB + off, w.Xs.p + off, sizeof(float) * (size_t)nloc * ld, hipMemcpyDeviceToDevice, st));
     if (iters) *iters = it;

@@ -35,6 +35,7 @@ struct glf_tuning {
     bool no_ecr = false;         // NO_ECR: column pass reads the per-column Ec fragment table instead of the compact one
     bool gs_seq = false;         // GS=seq: Gram-Schmidt as the column-by-column sweep instead of the Gram-matrix form
     bool residual_sweep = false; // RESIDUAL=sweep: residual from an explicit L_A sweep instead of the PCG state
+    bool no_narrow = false;      // NO_NARROW: block PCG applies the operator to all columns of the block even when few still iterate
     bool verbose = false;        // VERBOSE: log every outer iteration on stderr (the reference does, hpc/inverse_power_it.c:164-181)
 };
 
@@ -60,6 +61,7 @@ struct glf_ctx {
     hipEvent_t mv_ev[2][MV_RING] = {};
     int mv_pending = 0;
     int mv_count = 0;
+    int narrow_sweeps = 0; // L_A sweeps applied to a packed block of the still-active columns (block PCG)
     double mv_ms = 0.0, mv_bytes = 0.0;
     // the seeded random start block of the eigensolver (hpc/inverse_power_it.c:12-47) as a device [p64][ld] f32 block:
     // it depends on (p, m, ld, seed) only, so images of one size reuse it (17 ms of host time at cfg4)

@@ -65,7 +65,7 @@ int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *nu
 /* Kernel selection. Several stages have more than one implementation of the same sums (grid-factored vs entry by entry, two
  * row-pass shapes, ...); the default picks by problem size. key / value (value NULL, "" or "auto" = default):
  *   NYS_PATH, DEG_PATH  grid | direct        MV_PATH   grid | dense        ROWPASS, ROWPASS_OP  rt | v1
- *   NYS_NO_LUT, NO_ECR, VERBOSE  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
+ *   NYS_NO_LUT, NO_ECR, NO_NARROW, VERBOSE  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
  * At context creation each key is initialised from the environment variable GLF_<KEY> (read once; nothing reads the
  * environment per call). No reference counterpart (PETSc's -ksp_type / -pc_type options database is the nearest thing). */
 int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value);
