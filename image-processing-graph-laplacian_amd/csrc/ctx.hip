@@ -306,6 +306,7 @@ void glf_options_default(glf_options *opt)
     opt->kernel = GLF_KERNEL_BILATERAL;
     opt->filter_pow = 1;       // MatPow no-op, hpc/utils.c:721
     opt->filter_mode = GLF_FILTER_REFERENCE;
+    opt->filter_beta = 1.5f;
     opt->skip_exact_zeros = 0; // evaluate every entry, as the reference does
 }
 

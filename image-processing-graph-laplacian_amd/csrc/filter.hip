@@ -86,7 +86,7 @@ __device__ __forceinline__ uint8_t filter_output(int y, float c)
 // z[pix] = y + gain * sum_j Phi[pix][j] w[j]; LD/4 lanes per pixel, float4 each.
 template <int LD>
 __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict__ img, const float *__restrict__ phi,
-                                                       int64_t pix0, int64_t pix1, const float *__restrict__ w, float gain,
+                                                       int64_t pix0, int64_t pix1, const float *__restrict__ w, float gain, float ysub,
                                                        uint8_t *__restrict__ out, float *__restrict__ zf, float *__restrict__ corr)
 {
     constexpr int LPP = LD / 4;       // lanes per pixel (8 .. 64)
@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
         for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (q == 0) {
             const int y = (int)img[px];
-            const float c = gain * s;                // the correction 3.0 * Lapl_y, hpc/display.c:64-73
+            // the correction 3.0 * Lapl_y, hpc/display.c:64-73; ysub = 1 for the filters without a y term (z = Phi f Phi^T y):
+            // y is an integer, so y + floor(c - y) is the truncation of their z
+            const float c = gain * s - ysub * (float)y;
             if (zf) zf[px] = (float)y + c;           // MatAXPY(z, 3.0, Lapl_y) as a float (resolves c to ulp(z) only)
             if (corr) corr[px - pix0] = c;
             out[px] = filter_output(y, c);
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
 }
 
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1, unsigned /*m*/,
-                 unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf, float *d_corr)
+                 unsigned ld, const float *d_w, float gain, float ysub, uint8_t *d_out, float *d_zf, float *d_corr)
 {
     if (!valid_ld(ld) || pix0 > pix1) return set_error(ctx, GLF_ERR_INVALID, "apply_filter: ld=%u", ld);
     if (pix0 == pix1) return GLF_OK;
@@ -118,10 +120,10 @@ int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t
     if (nblk > 8192) nblk = 8192; // grid-stride the rest
     dim3 grid((unsigned)nblk), block(256);
     switch (ld) {
-    case 32: hipLaunchKernelGGL(k_apply_filter<32>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
-    case 64: hipLaunchKernelGGL(k_apply_filter<64>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
-    case 128: hipLaunchKernelGGL(k_apply_filter<128>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
-    case 256: hipLaunchKernelGGL(k_apply_filter<256>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, d_out, d_zf, d_corr); break;
+    case 32: hipLaunchKernelGGL(k_apply_filter<32>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, ysub, d_out, d_zf, d_corr); break;
+    case 64: hipLaunchKernelGGL(k_apply_filter<64>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, ysub, d_out, d_zf, d_corr); break;
+    case 128: hipLaunchKernelGGL(k_apply_filter<128>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, ysub, d_out, d_zf, d_corr); break;
+    case 256: hipLaunchKernelGGL(k_apply_filter<256>, grid, block, 0, ctx->stream, d_img, d_phi, pix0, pix1, d_w, gain, ysub, d_out, d_zf, d_corr); break;
     }
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
@@ -144,12 +146,13 @@ __global__ __launch_bounds__(256) void k_filter_accum(const float *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_filter_finish(const uint8_t *__restrict__ img, const float *__restrict__ acc, int64_t pix0,
-                                                        int64_t pix1, float gain, uint8_t *__restrict__ out, float *__restrict__ zf)
+                                                        int64_t pix1, float gain, float ysub, uint8_t *__restrict__ out,
+                                                        float *__restrict__ zf)
 {
     const int64_t px = pix0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (px >= pix1) return;
     const int y = (int)img[px];
-    const float c = gain * acc[px - pix0];
+    const float c = gain * acc[px - pix0] - ysub * (float)y;
     if (zf) zf[px] = (float)y + c;
     out[px] = filter_output(y, c);
 }
@@ -166,11 +169,12 @@ int filter_accumulate(glf_ctx *ctx, const float *d_phi, int64_t pix0, int64_t pi
     return GLF_OK;
 }
 
-int filter_finish(glf_ctx *ctx, const uint8_t *d_img, const float *d_acc, int64_t pix0, int64_t pix1, float gain, uint8_t *d_out, float *d_zf)
+int filter_finish(glf_ctx *ctx, const uint8_t *d_img, const float *d_acc, int64_t pix0, int64_t pix1, float gain, float ysub, uint8_t *d_out,
+                  float *d_zf)
 {
     if (pix0 >= pix1) return GLF_OK;
     hipLaunchKernelGGL(k_filter_finish, dim3((unsigned)ceil_div(pix1 - pix0, 256)), dim3(256), 0, ctx->stream, d_img, d_acc, pix0, pix1, gain,
-                       d_out, d_zf);
+                       ysub, d_out, d_zf);
     GLF_LAUNCH_CHECK(ctx);
     return GLF_OK;
 }

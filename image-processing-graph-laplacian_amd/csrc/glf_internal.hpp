@@ -362,11 +362,12 @@ int permute_rows(glf_ctx *ctx, const float *d_in, float *d_out, int64_t N, unsig
 int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0, int64_t pix1, unsigned m,
             unsigned ld, double *d_c);
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1,
-                 unsigned m, unsigned ld, const float *d_w, float gain, uint8_t *d_out, float *d_zf, float *d_corr = nullptr);
-// the same filter panel by panel (m > 256): acc[px - pix0] (+)= sum_j Phi[px][j] w[j], then z = y + gain * acc
+                 unsigned m, unsigned ld, const float *d_w, float gain, float ysub, uint8_t *d_out, float *d_zf,
+                 float *d_corr = nullptr);
+// the same filter panel by panel (m > 256): acc[px - pix0] (+)= sum_j Phi[px][j] w[j], then z = (1 - ysub) y + gain * acc
 int filter_accumulate(glf_ctx *ctx, const float *d_phi, int64_t pix0, int64_t pix1, unsigned ld, const float *d_w, float *d_acc,
                       bool first);
-int filter_finish(glf_ctx *ctx, const uint8_t *d_img, const float *d_acc, int64_t pix0, int64_t pix1, float gain, uint8_t *d_out,
-                  float *d_zf);
+int filter_finish(glf_ctx *ctx, const uint8_t *d_img, const float *d_acc, int64_t pix0, int64_t pix1, float gain, float ysub,
+                  uint8_t *d_out, float *d_zf);
 
 } // namespace glf

@@ -415,7 +415,7 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
             GLF_TRY(glf_memcpy_h2d(ctx, wq.p, hw.data(), sizeof(float) * PANEL_COLS));
             GLF_TRY(filter_accumulate(ctx, pan.p, 0, N, PANEL_COLS, wq.p, acc.p, q == 0));
         }
-        GLF_TRY(filter_finish(ctx, d_img, acc.p, 0, N, gain, d_out, d_zf));
+        GLF_TRY(filter_finish(ctx, d_img, acc.p, 0, N, gain, 0.f, d_out, d_zf));
         GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return GLF_OK;
     }
@@ -430,7 +430,7 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
     DevBuf<float> w;
     GLF_TRY(w.alloc(ctx, ld));
     GLF_TRY(glf_memcpy_h2d(ctx, w.p, hw.data(), sizeof(float) * ld));
-    GLF_TRY(apply_filter(ctx, d_img, phi->data, 0, N, m, ld, w.p, gain, d_out, d_zf));
+    GLF_TRY(apply_filter(ctx, d_img, phi->data, 0, N, m, ld, w.p, gain, 0.f, d_out, d_zf));
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;
 }
@@ -469,13 +469,23 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         opt = *opt_in;
     }
     if (opt.kernel < GLF_KERNEL_BILATERAL || opt.kernel > GLF_KERNEL_NLM) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", opt.kernel);
-    if (opt.filter_mode != GLF_FILTER_REFERENCE && opt.filter_mode != GLF_FILTER_POC) return set_error(ctx, GLF_ERR_INVALID, "filter_mode %d", opt.filter_mode);
-    // f(Pi) and the gain of the filter: the reference's z = y + gain Phi Pi^k Phi^T y (MatPow is a no-op there, hpc/utils.c:721 => k = 1),
-    // or the PoC's z = y - Phi diag(mu + 5) Phi^T y (python/image_processing.py:304-305)
-    const bool poc_filter = opt.filter_mode == GLF_FILTER_POC;
-    const float filter_gain = poc_filter ? 1.0f : opt.gain;
+    if (opt.filter_mode < GLF_FILTER_REFERENCE || opt.filter_mode > GLF_FILTER_SHARPEN) return set_error(ctx, GLF_ERR_INVALID, "filter_mode %d", opt.filter_mode);
+    // f(Pi), the gain and the y term of the filter z = ysub' y + gain Phi f(Pi) Phi^T y:
+    //   reference: z = y + gain Phi Pi^k Phi^T y (MatPow is a no-op there, hpc/utils.c:721 => k = 1);
+    //   PoC: z = y - Phi diag(mu + 5) Phi^T y (python/image_processing.py:304-305);
+    //   smoothing / sharpening (:197-241): z = Phi f(s) Phi^T y with s = 1 - mu the eigenvalues of W = I - L, f(s) = s or
+    //   (1 + beta) s^2 - beta s^3 -- no y term: the kernels subtract it from the correction (filter_ysub).
+    const bool ref_filter = opt.filter_mode == GLF_FILTER_REFERENCE;
+    const float filter_gain = ref_filter ? opt.gain : 1.0f;
+    const float filter_ysub = opt.filter_mode >= GLF_FILTER_SMOOTH ? 1.0f : 0.0f;
     auto filter_weight = [&](double lambda) {
-        return poc_filter ? -(lambda + 5.0) : std::pow(lambda, (double)(opt.filter_pow > 0 ? opt.filter_pow : 1));
+        const double s1 = 1.0 - lambda, beta = (double)opt.filter_beta;
+        switch (opt.filter_mode) {
+        case GLF_FILTER_POC: return -(lambda + 5.0);
+        case GLF_FILTER_SMOOTH: return s1;
+        case GLF_FILTER_SHARPEN: return (1.0 + beta) * s1 * s1 - beta * s1 * s1 * s1;
+        default: return std::pow(lambda, (double)(opt.filter_pow > 0 ? opt.filter_pow : 1));
+        }
     };
     const int64_t N = (int64_t)width * height;
     if (N >= (int64_t)1 << 31) return set_error(ctx, GLF_ERR_UNSUPPORTED, "image too large");
@@ -657,7 +667,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
             GLF_TRY(filter_accumulate(ctx, phiw.p, pix0, pix1, PANEL_COLS, ww.p, acc.p, q == 0));
         }
         GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));
-        GLF_TRY(filter_finish(ctx, d_img, acc.p, pix0, pix1, filter_gain, d_out, d_zf));
+        GLF_TRY(filter_finish(ctx, d_img, acc.p, pix0, pix1, filter_gain, filter_ysub, d_out, d_zf));
         GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
         GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
         S.nystroem_launches = (int)npan;
@@ -747,7 +757,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         GLF_HIP(ctx, hipMemcpyAsync(w.p, hw.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }
-    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, filter_gain, d_out, d_zf, cap ? cap->d_corr : nullptr));
+    GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, filter_gain, filter_ysub, d_out, d_zf, cap ? cap->d_corr : nullptr));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
     GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
     GLF_HIP(ctx, hipEventElapsedTime(&S.ms_affinity, ctx->ev[0], ctx->ev[1]));

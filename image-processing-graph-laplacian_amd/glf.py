@@ -34,7 +34,7 @@ MAT_DENSE, MAT_DIAG, MAT_KERNEL_B = 0, 1, 2
 ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
 KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL, KERNEL_NLM = 0, 1, 2, 3
 CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
-FILTER_REFERENCE, FILTER_POC = 0, 1
+FILTER_REFERENCE, FILTER_POC, FILTER_SMOOTH, FILTER_SHARPEN = 0, 1, 2, 3
 MULTI_RCCL, MULTI_LOOPBACK = 0, 1
 RCCL_ID_BYTES = 128
 
@@ -73,7 +73,7 @@ class Options(C.Structure):
         ("num_eigvals", C.c_uint32), ("opti_gs", C.c_int32), ("epsilon", C.c_double),
         ("inner_rtol", C.c_double), ("max_outer", C.c_int32), ("seed", C.c_uint64), ("gain", C.c_float),
         ("h_loc", C.c_float), ("h_val", C.c_float), ("kernel", C.c_int32), ("filter_pow", C.c_int32),
-        ("filter_mode", C.c_int32), ("skip_exact_zeros", C.c_int32),
+        ("filter_mode", C.c_int32), ("skip_exact_zeros", C.c_int32), ("filter_beta", C.c_float),
     ]
 
 

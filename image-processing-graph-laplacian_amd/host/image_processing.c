@@ -8,9 +8,11 @@
  *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
  *                    [-dump_eigvecs] [-ngpu N [-ngpu_backend rccl|loopback]] [-filter_pow K]
  *                    [-kernel bilateral|photometric|spatial|nlm] [-h_loc X] [-h_val X] [-gain X] [-dump_residual]
- *                    [-filter reference|poc] [-color]
+ *                    [-filter reference|poc|smooth|sharpen [-sharpen_beta B]] [-color]
  * -filter poc applies the Python PoC's active filter z = y - Phi diag(mu + 5) Phi^T y (python/image_processing.py:304-305) instead
- * of hpc/display.c:58-83. -color keeps the colours of an RGB(A) input the way the PoC does (python/image_processing.py:410-432):
+ * of hpc/display.c:58-83; -filter smooth / sharpen the PoC's `smoothing` z = W y and `sharpening` z = (1 + B) W^2 y - B W^3 y
+ * (python/image_processing.py:197-241, B = 1.5) with W = Phi diag(1 - mu) Phi^T from the eigenpairs this program computes.
+ * -color keeps the colours of an RGB(A) input the way the PoC does (python/image_processing.py:410-432):
  * RGB -> YUV (python/utils.py:33-44), the luma plane is filtered, the chroma planes pass through, YUV -> RGB; the luma is
  * rounded to 8 bits first because every kernel here works on u8 pixel values (the PoC filters the unrounded floats).
  * -dump_residual writes results/residuals.png = |input - output| stretched to the full grey range, the PoC's residual image
@@ -235,7 +237,12 @@ static void fill_options(glf_options *opt, unsigned width, unsigned height)
     opt->h_val = stage_h_val;
     opt->gain = stage_gain;
     if ((v = opt_value("-filter_pow")) && atoi(v) > 0) opt->filter_pow = atoi(v);
-    if ((v = opt_value("-filter")) && strcmp(v, "poc") == 0) opt->filter_mode = GLF_FILTER_POC;
+    if ((v = opt_value("-filter"))) {
+        if (strcmp(v, "poc") == 0) opt->filter_mode = GLF_FILTER_POC;
+        else if (strcmp(v, "smooth") == 0) opt->filter_mode = GLF_FILTER_SMOOTH;
+        else if (strcmp(v, "sharpen") == 0) opt->filter_mode = GLF_FILTER_SHARPEN;
+    }
+    if ((v = opt_value("-sharpen_beta"))) opt->filter_beta = (float)atof(v);
 }
 
 static void print_stage_times(const glf_stats *st, double epsilon)

@@ -263,7 +263,7 @@ int glf_ComputeResultFromLaplacian(glf_ctx *ctx, const uint8_t *d_img, const glf
 
 /* ---- whole path ----------------------------------------------------------------- */
 
-enum { GLF_FILTER_REFERENCE = 0, GLF_FILTER_POC = 1 };
+enum { GLF_FILTER_REFERENCE = 0, GLF_FILTER_POC = 1, GLF_FILTER_SMOOTH = 2, GLF_FILTER_SHARPEN = 3 };
 typedef struct glf_options {
     uint32_t struct_size;   /* sizeof(glf_options) */
     uint32_t num_samples;   /* requested sample count; 0 -> width*height*sample_frac (hpc/image_processing.c:187) */
@@ -280,11 +280,17 @@ typedef struct glf_options {
     int32_t filter_pow;     /* 1: f(Pi) = Pi (MatPow is a no-op, hpc/utils.c:721); k: Pi^k */
     int32_t filter_mode;    /* GLF_FILTER_REFERENCE (0): z = y + gain Phi Pi^filter_pow Phi^T y, clamp, cast (hpc/display.c:58-83);
                                GLF_FILTER_POC (1): the Python PoC's active filter z = y - Phi diag(mu + 5) Phi^T y
-                               (python/image_processing.py:304-305; gain and filter_pow ignored), same clamp and cast */
+                               (python/image_processing.py:304-305; gain and filter_pow ignored), same clamp and cast;
+                               GLF_FILTER_SMOOTH (2): z = Phi diag(1 - mu) Phi^T y -- the PoC's `smoothing` (:197-219), W = I - L with
+                               the eigenpairs of the renormalised Laplacian this path computes (W's are (1 - mu, the same vectors);
+                               the PoC takes them by a dense eigh of W_A and the same Nystroem extension);
+                               GLF_FILTER_SHARPEN (3): z = (1 + beta) W^2 y - beta W^3 y (:222-241) as Phi diag((1 + beta) s^2 -
+                               beta s^3) Phi^T y, s = 1 - mu, beta = filter_beta. Neither adds y; gain and filter_pow ignored */
     int32_t skip_exact_zeros; /* 0 (default): every K_B / K_A entry is evaluated, as the reference does.
                                  1: entries that are exactly zero in the arithmetic in use (pixel-sample
                                  distance beyond the radius where exp underflows) are skipped in whole tiles;
                                  the output is bit-identical, the work is not -- see glf_stats.*_evaluated. */
+    float filter_beta;      /* GLF_FILTER_SHARPEN: 1.5 (python/image_processing.py:231) */
 } glf_options;
 void glf_options_default(glf_options *opt);
 

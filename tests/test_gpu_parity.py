@@ -813,3 +813,36 @@ def test_batch_throughput_mode_is_bit_identical_to_single_calls(ctx):
     finally:
         for c in extra:
             c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["smooth", "sharpen"])
+def test_smoothing_and_sharpening_filters(ctx, png, mode):
+    """f4: the PoC's `smoothing` (z = W y) and `sharpening` (z = (1 + beta) W^2 y - beta W^3 y, beta = 1.5)
+    (python/image_processing.py:197-241) in spectral form on the eigenpairs of this path: W = I - L has the eigenvalues
+    1 - mu with the same vectors, so z = Phi f(1 - mu) Phi^T y. Checked against the fp64 oracle fed the same eigenpairs
+    (orc.result_from_laplacian computes y + Phi f Phi^T y; the y term is taken out again)."""
+    img = np.ascontiguousarray(png("test.png"))
+    if img.ndim == 3:
+        img = np.ascontiguousarray(img[:, :, 0])
+    h, w = img.shape
+    beta = 1.5
+    opt = glf.default_options(num_samples=100, num_eigvals=16, epsilon=0.1,
+                              filter_mode=glf.FILTER_SMOOTH if mode == "smooth" else glf.FILTER_SHARPEN, filter_beta=beta)
+    d_img = ctx.to_device(img)
+    out, zf, info = ctx.image_processing(d_img, opt, want_float=True, capture=True)
+    out, zf = out.cpu().numpy(), zf.cpu().numpy()
+    lam = np.asarray(info["eigvals"], dtype=np.float64)
+    s1 = 1.0 - lam
+    f = s1 if mode == "smooth" else (1.0 + beta) * s1 ** 2 - beta * s1 ** 3
+    phi = info["capture"]["phi"].cpu().numpy().astype(np.float64)   # [N, ld] raster rows as the filter kernel read them
+    m = lam.size
+    zref, _ = orc.result_from_laplacian(img, np.ascontiguousarray(phi[:, :m].T), f, gain=1.0)
+    zref = zref.reshape(h, w) - img.astype(np.float64)   # no y term in these filters
+    ref8 = np.clip(zref, 0.0, 255.0).astype(np.uint8)
+    assert np.max(np.abs(zf.astype(np.float64) - zref)) <= 2e-3 * max(1.0, np.max(np.abs(zref)))
+    assert np.mean(out == ref8) >= 0.999 and np.max(np.abs(out.astype(int) - ref8.astype(int))) <= 1
+    # the filters do what their names say: smoothing lowers the total variation of the image, sharpening raises it above that
+    tv = lambda a: float(np.abs(np.diff(a.astype(np.float64), axis=1)).sum())
+    if mode == "smooth":
+        assert tv(zf) < tv(img)

@@ -213,15 +213,15 @@ YUV_FROM_RGB = np.array([[0.299, 0.587, 0.114], [-0.14714119, -0.28886916, 0.436
 @pytest.mark.gpu
 def test_color_and_poc_filter(tmp_path):
     """-color: the PoC's colour handling (python/image_processing.py:410-432): RGB -> YUV, the luma is filtered, the chroma
-    kept, YUV -> RGB; -filter poc: its active filter z = y - Phi diag(mu + 5) Phi^T y (:304-305). Emulated here with the oracle's
-    stages on the 8-bit luma."""
+    kept, YUV -> RGB; -filter poc: its active filter z = y - Phi diag(mu + 5) Phi^T y (:304-305); -filter smooth / sharpen: its
+    `smoothing` and `sharpening` (:197-241) in spectral form. Emulated here with the oracle's stages on the 8-bit luma."""
     src = os.path.join(ROOT, "tests", "golden", "pixel_mountains.png")
     rgb = glf.read_png_rgb(src).astype(np.float64)
     h, w, _ = rgb.shape
     yuv = rgb @ YUV_FROM_RGB.T
     luma = np.clip(np.floor(yuv[:, :, 0] + 0.5), 0, 255).astype(np.uint8)
     ns, m = 300, 16
-    for flt in ("reference", "poc"):
+    for flt in ("reference", "poc", "smooth", "sharpen"):
         d = str(tmp_path / flt)
         r = _run(["-f", src, "-color", "-num_samples", str(ns), "-num_eigvals", str(m), "-filter", flt], d)
         assert r.returncode == 0, r.stderr.decode()
@@ -236,8 +236,12 @@ def test_color_and_poc_filter(tmp_path):
         phi = orc.permutation(orc.nystroem(luma, idx, alpha, vecs, vals), idx)
         if flt == "reference":
             zf, _ = orc.result_from_laplacian(luma, phi, vals, gain=3.0)
-        else:
+        elif flt == "poc":
             zf, _ = orc.result_from_laplacian(luma, phi, -(vals + 5.0), gain=1.0)
+        else:  # smoothing z = W y, sharpening z = 2.5 W^2 y - 1.5 W^3 y (python/image_processing.py:197-241), W = Phi (1 - mu) Phi^T
+            s1 = 1.0 - vals
+            f = s1 if flt == "smooth" else 2.5 * s1 ** 2 - 1.5 * s1 ** 3
+            zf = orc.result_from_laplacian(luma, phi, f, gain=1.0)[0] - luma.astype(np.float64)
         z = np.stack([zf, yuv[:, :, 1], yuv[:, :, 2]], axis=2) @ np.linalg.inv(YUV_FROM_RGB).T
         ref = np.clip(z, 0, 255).astype(np.uint8).astype(np.float64)
         assert psnr(out, ref) >= 45.0, flt
