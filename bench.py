@@ -234,9 +234,28 @@ def main():
     ctx = glf.Context(local_rank)
     if world > 1 or args.force_comm:
         if args.comm == "rccl":   # the library issues its own RCCL collectives: the id travels through torch.distributed once
-            box = [glf.rccl_unique_id() if rank == 0 else None]
+            ok = 1
+            try:
+                box = [glf.rccl_unique_id() if rank == 0 else None]
+            except Exception as e:                      # librccl not loadable on this rank
+                box, ok = [None], 0
+                print("rank %d: %s" % (rank, e), file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            ctx.set_comm_rccl(rank, world, box[0], force=args.force_comm)
+            if ok and box[0] is not None:
+                try:
+                    ctx.set_comm_rccl(rank, world, box[0], force=args.force_comm)
+                except Exception as e:
+                    ok = 0
+                    print("rank %d: %s" % (rank, e), file=sys.stderr)
+            else:
+                ok = 0
+            # every rank takes the same route: if the library's own communicator could not be set up anywhere, all ranks fall
+            # back to the torch.distributed callbacks (and the bench line says so)
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctx.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                args.comm = "torch"
+                ctx.set_comm_torch(force=args.force_comm)
         else:
             ctx.set_comm_torch(force=args.force_comm)
     d_img = ctx.to_device(img)
