@@ -117,6 +117,15 @@ int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value)
     return GLF_OK;
 }
 
+size_t glf_ctx_cached_bytes(const glf_ctx *ctx)
+{
+    size_t total = 0;
+    if (ctx)
+        for (const glf_pool_block &b : ctx->pool)
+            if (!b.in_use) total += b.bytes;
+    return total;
+}
+
 int glf_ctx_debug_violations(const glf_ctx *ctx)
 {
     if (!ctx || !ctx->pool_debug) return -1;
@@ -339,6 +348,8 @@ static void pool_check_guard(glf_ctx *ctx, const glf_pool_block &b, const char *
     }
 }
 
+void pool_age(glf_ctx *ctx);
+
 void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan)
 {
     (void)hipSetDevice(ctx->device);
@@ -352,7 +363,7 @@ void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan)
         }
         (void)hipMemsetAsync(p, poison_nan ? 0xFF : 0x00, need, ctx->stream); // 0xFF...: NaN as f16, f32 and f64
         (void)hipMemsetAsync(static_cast<char *>(p) + need, POOL_CANARY, POOL_GUARD_BYTES, ctx->stream);
-        ctx->pool.push_back(glf_pool_block{p, need, true});
+        ctx->pool.push_back(glf_pool_block{p, need, true, ctx->call_no});
         return p;
     }
     int best = -1;
@@ -363,8 +374,10 @@ void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan)
     }
     if (best >= 0) {
         ctx->pool[best].in_use = true;
+        ctx->pool[best].last_call = ctx->call_no;
         return ctx->pool[best].p;
     }
+    pool_age(ctx); // a miss: before growing, give back what no call has taken for a while
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, need);
     if (e != hipSuccess) { // make room: drop every cached block nobody is using, then retry once
@@ -378,8 +391,25 @@ void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan)
         set_error(ctx, GLF_ERR_NOMEM, "hipMalloc(%zu bytes) -> %s", need, hipGetErrorString(e));
         return nullptr;
     }
-    ctx->pool.push_back(glf_pool_block{p, need, true});
+    ctx->pool.push_back(glf_pool_block{p, need, true, ctx->call_no});
     return p;
+}
+
+// Returns the cached blocks no call has taken for POOL_KEEP_CALLS public calls to the driver: a process that walks through many
+// image sizes would otherwise keep every size's work buffers for the life of the context. Called on every pool miss and at
+// the start of the whole-path entry points.
+void pool_age(glf_ctx *ctx)
+{
+    if (ctx->pool_debug) return; // (the debug pool caches nothing)
+    for (size_t i = 0; i < ctx->pool.size();) {
+        const glf_pool_block &b = ctx->pool[i];
+        if (!b.in_use && ctx->call_no - b.last_call > POOL_KEEP_CALLS) {
+            (void)hipFree(b.p); // (waits for work that may still read it)
+            ctx->pool.erase(ctx->pool.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
 }
 
 void pool_put(glf_ctx *ctx, void *ptr)

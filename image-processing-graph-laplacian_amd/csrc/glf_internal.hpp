@@ -20,6 +20,7 @@ struct glf_pool_block {
     void *p;
     size_t bytes;     // usable bytes (debug pool: the exact request rounded up to 256; a guard zone follows)
     bool in_use;
+    unsigned last_call = 0; // glf_ctx::call_no of the public call that last took the block
 };
 
 // Which of several equivalent kernels implements a stage. Defaults (0 / false) = chosen from the problem size; every choice
@@ -60,6 +61,7 @@ struct glf_ctx {
     static constexpr int MV_RING = 64;
     hipEvent_t mv_ev[2][MV_RING] = {};
     int mv_pending = 0;
+    unsigned call_no = 0; // public entry points so far (ages the cached work buffers: pool_get)
     int mv_count = 0;
     int narrow_sweeps = 0; // L_A sweeps applied to a packed block of the still-active columns (block PCG)
     double mv_ms = 0.0, mv_bytes = 0.0;
@@ -121,7 +123,11 @@ inline int set_error(glf_ctx *ctx, int status, const char *fmt, ...)
 #define GLF_LAUNCH_CHECK(ctx) GLF_HIP(ctx, hipGetLastError())
 // every public entry point: the calling thread's current device becomes the context's (two contexts on different GPUs in
 // one process, or one host thread per GPU in glf_multi_*, would otherwise allocate and launch on the wrong device)
-#define GLF_ENTER(ctx) GLF_HIP(ctx, hipSetDevice((ctx)->device))
+#define GLF_ENTER(ctx)                                 \
+    do {                                               \
+        GLF_HIP(ctx, hipSetDevice((ctx)->device));     \
+        ++(ctx)->call_no;                              \
+    } while (0)
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 inline int64_t ceil_div(int64_t x, int64_t q) { return (x + q - 1) / q; }
@@ -136,6 +142,7 @@ inline bool wide_ld(unsigned ld) { return ld > PANEL_COLS && ld % PANEL_COLS == 
 inline unsigned ld_total_for(unsigned m) { return m <= PANEL_COLS ? ld_for(m) : (unsigned)round_up(m, PANEL_COLS); }
 
 constexpr size_t POOL_GUARD_BYTES = 4096;            // debug pool: canary bytes after every block
+constexpr unsigned POOL_KEEP_CALLS = 64;             // an unused cached work buffer survives this many public calls without being taken
 constexpr int POOL_CANARY = 0xA5;
 // poison: the block holds floating-point data (debug pool: handed out filled with NaN; integer blocks with zeros)
 void native_comm_release(glf_ctx *ctx);              // comm.hip
@@ -143,6 +150,7 @@ void *pool_get(glf_ctx *ctx, size_t bytes, bool poison_nan = false); // nullptr 
 void pool_put(glf_ctx *ctx, void *ptr);              // back to the pool
 void pool_forget(glf_ctx *ctx, void *ptr);           // ownership leaves the pool (caller hipFree's it)
 void pool_free_all(glf_ctx *ctx, bool only_unused);
+void pool_age(glf_ctx *ctx);                         // frees the cached blocks no call has taken for POOL_KEEP_CALLS public calls
 
 // RAII device buffer from the context's workspace pool (returned to the pool at scope exit).
 template <typename T>

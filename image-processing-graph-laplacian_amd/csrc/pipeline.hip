@@ -461,6 +461,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     if (cap && cap->struct_size != sizeof(glf_capture))
         return set_error(ctx, GLF_ERR_INVALID, "glf_capture.struct_size %u != %zu", cap->struct_size, sizeof(glf_capture));
     GLF_ENTER(ctx);
+    pool_age(ctx);
     glf_options opt;
     glf_options_default(&opt);
     if (opt_in) {

@@ -47,7 +47,7 @@ EXPORTS = [
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
     "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
-    "glf_options_default", "glf_image_processing", "glf_image_processing_capture", "glf_ctx_debug_violations", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png", "glf_read_png_rgb", "glf_write_png_rgb",
+    "glf_options_default", "glf_image_processing", "glf_image_processing_capture", "glf_ctx_debug_violations", "glf_ctx_cached_bytes", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png", "glf_read_png_rgb", "glf_write_png_rgb",
 ]
 
 
@@ -114,6 +114,8 @@ _lib.glf_multi_ctx.restype = C.c_void_p
 _lib.glf_multi_last_error.restype = C.c_char_p
 _lib.glf_multi_last_error.argtypes = [C.c_void_p]
 _lib.glf_options_default.restype = None
+_lib.glf_ctx_cached_bytes.restype = C.c_size_t
+_lib.glf_ctx_cached_bytes.argtypes = [C.c_void_p]
 
 
 class GlfError(RuntimeError):
@@ -357,6 +359,10 @@ class Context:
     def debug_violations(self):
         """Guard zones of work buffers found overwritten (debug pool, GLF_POOL_DEBUG=1 at creation); -1 otherwise."""
         return int(_lib.glf_ctx_debug_violations(self._ctx))
+
+    def cached_bytes(self):
+        """Bytes of work buffers the context keeps cached and unused (glf_ctx_cached_bytes)."""
+        return int(_lib.glf_ctx_cached_bytes(self._ctx))
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -75,6 +75,10 @@ int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value);
  * verified when the buffer is released. Returns the number of guard zones found overwritten so far (0 = no kernel
  * wrote past the end of a work buffer), -1 when the context was not created in debug mode. */
 int glf_ctx_debug_violations(const glf_ctx *ctx);
+/* Work buffers are cached between calls (a second image of the same size allocates nothing). Bytes currently cached and not
+ * in use; a cached buffer that no call has taken for 64 public calls is returned to the driver at the next allocation, so a
+ * process that walks through many image sizes does not keep every size's buffers. No reference counterpart. */
+size_t glf_ctx_cached_bytes(const glf_ctx *ctx);
 
 /* Collectives supplied by the caller (replace the MPI_Allreduce / allgather
  * inside PETSc's VecDot, VecSum, MatMult: hpc/gram_schmidt.c:14-15,

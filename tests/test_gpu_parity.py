@@ -846,3 +846,24 @@ def test_smoothing_and_sharpening_filters(ctx, png, mode):
     tv = lambda a: float(np.abs(np.diff(a.astype(np.float64), axis=1)).sum())
     if mode == "smooth":
         assert tv(zf) < tv(img)
+
+
+@pytest.mark.gpu
+def test_cached_work_buffers_age_out():
+    """The workspace pool keeps a call's buffers for the next image of the same size, but not for ever: buffers no call has
+    taken for 64 public calls are returned at the next allocation (a service that walks through many image sizes must not
+    keep every size's buffers)."""
+    c = glf.Context(0)
+    try:
+        big = glf.synth_image(512, 512, seed=2)
+        c.image_processing(c.to_device(big), glf.default_options(num_samples=2600, num_eigvals=32, epsilon=0.1))
+        after_big = c.cached_bytes()
+        assert after_big > 50 << 20                     # tens of MB of K_A / L_A / vector blocks are cached
+        c.image_processing(c.to_device(big), glf.default_options(num_samples=2600, num_eigvals=32, epsilon=0.1))
+        assert c.cached_bytes() == after_big            # the same size again allocates nothing
+        for i in range(80):                             # 80 calls on small images of changing size: misses trigger the sweep
+            s = 32 + 8 * (i % 10)
+            c.image_processing(c.to_device(glf.synth_image(s, s, seed=i)), glf.default_options(num_samples=16, num_eigvals=4, epsilon=0.1))
+        assert c.cached_bytes() < after_big // 4
+    finally:
+        c.close()
