@@ -1785,7 +1785,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
     GLF_LAUNCH_CHECK(ctx);
 
     GLF_TRY(mv_collect(ctx));
-    const int mv_count0 = ctx->mv_count;
+    const int mv_count0 = ctx->mv_count, narrow0 = ctx->narrow_sweeps;
     const double mv_ms0 = ctx->mv_ms, mv_bytes0 = ctx->mv_bytes;
     bool replicated = false;
     GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld, rows, shard, &replicated)); // :95
@@ -1850,6 +1850,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         stats->matvecs = ctx->mv_count - mv_count0;
         stats->matvec_ms = (float)(ctx->mv_ms - mv_ms0);
         stats->matvec_bytes = ctx->mv_bytes - mv_bytes0;
+        stats->narrow_sweeps = ctx->narrow_sweeps - narrow0;
     }
     return rc;
 }
@@ -1987,7 +1988,7 @@ int inverse_power_iteration_panels(glf_ctx *ctx, const float *A, int64_t lda, un
     else hipLaunchKernelGGL(k_diag_inv, dim3((p + 255) / 256), dim3(256), 0, st, A, lda, p, cg.dinv.p);
     GLF_LAUNCH_CHECK(ctx);
     GLF_TRY(mv_collect(ctx));
-    const int mv_count0 = ctx->mv_count;
+    const int mv_count0 = ctx->mv_count, narrow0 = ctx->narrow_sweeps;
     const double mv_ms0 = ctx->mv_ms, mv_bytes0 = ctx->mv_bytes;
 
     GLF_TRY(panels_orthonormalise(ctx, gs, pw, X.p, pstride, p, m, norms.p)); // :95
@@ -2036,6 +2037,7 @@ int inverse_power_iteration_panels(glf_ctx *ctx, const float *A, int64_t lda, un
         stats->matvecs = ctx->mv_count - mv_count0;
         stats->matvec_ms = (float)(ctx->mv_ms - mv_ms0);
         stats->matvec_bytes = ctx->mv_bytes - mv_bytes0;
+        stats->narrow_sweeps = ctx->narrow_sweeps - narrow0;
     }
     return rc;
 }

@@ -64,7 +64,8 @@ class Mat(C.Structure):
 
 class EigStats(C.Structure):
     _fields_ = [("outer_its", C.c_int32), ("inner_its_total", C.c_int32), ("residual", C.c_double),
-                ("matvecs", C.c_int32), ("matvec_ms", C.c_float), ("matvec_bytes", C.c_double)]
+                ("matvecs", C.c_int32), ("matvec_ms", C.c_float), ("matvec_bytes", C.c_double),
+                ("narrow_sweeps", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -625,6 +626,7 @@ class Context:
                     nystroem_rowpass_launches=st.nystroem_rowpass_launches, nystroem_rowpass_ms=st.nystroem_rowpass_ms,
                     nystroem_rowpass_flops=st.nystroem_rowpass_flops,
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
+                    narrow_sweeps=st.eig.narrow_sweeps,
                     eigvals=lam[:st.m].copy())
         if capture:
             assert cap.ld == keep[0].shape[1], (cap.ld, keep[0].shape)

@@ -224,6 +224,8 @@ typedef struct glf_eig_stats {
     int32_t matvecs;
     float matvec_ms;
     double matvec_bytes;
+    int32_t narrow_sweeps;  /* of those sweeps, the ones applied to a packed block of the still-iterating columns only (block PCG) */
+    int32_t reserved;
 } glf_eig_stats;
 
 /* void InversePowerIteration(const Mat A, unsigned m, Mat* eigvecs, Mat* eigvals,

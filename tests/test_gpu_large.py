@@ -247,3 +247,28 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
         ctx.destroy(L_A, vecs, vals, Pi_inv, K_B)
     _record("arithmetic_%d.json" % size, report)
     print(json.dumps(report, default=float))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,m", [(1024, 64), (1024, 100)])
+def test_narrow_sweeps_return_the_same_numbers(size, m):
+    """Block PCG applies the operator to the still-iterating columns only once few are left (packed into a block of 32
+    columns, or of a multiple of 64 below ld): the operator's columns are independent, so eigenvalues and the filtered image
+    must come out bit for bit as with full-width sweeps (GLF_NO_NARROW), and the narrow sweeps must actually occur."""
+    img = glf.synth_image(size, size, seed=5)
+    res = {}
+    for narrow in (True, False):
+        c = glf.Context(0)
+        try:
+            c.set_tuning(NO_NARROW="0" if narrow else "1", MV_PATH="grid")
+            opt = glf.default_options(num_samples=int(size * size * 0.005), num_eigvals=m, epsilon=0.05)
+            out, zf, info = c.image_processing(c.to_device(img), opt, want_float=True)
+            res[narrow] = (out.cpu().numpy(), zf.cpu().numpy(), info)
+        finally:
+            c.close()
+    a, b = res[True], res[False]
+    assert a[2]["narrow_sweeps"] > 0 and b[2]["narrow_sweeps"] == 0
+    assert a[2]["outer_its"] == b[2]["outer_its"] and a[2]["matvecs"] == b[2]["matvecs"]
+    np.testing.assert_array_equal(a[2]["eigvals"].view(np.int64), b[2]["eigvals"].view(np.int64))
+    np.testing.assert_array_equal(a[1].view(np.int32), b[1].view(np.int32))
+    np.testing.assert_array_equal(a[0], b[0])
