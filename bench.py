@@ -277,13 +277,14 @@ def main():
         barrier()
         t0 = time.perf_counter()
         kernel_ms = []
-        mv = {"launches": 0, "ms": 0.0, "bytes": 0.0}
+        mv = {"launches": 0, "ms": 0.0, "bytes": 0.0, "narrow": 0}
         rp = {"launches": 0, "ms": 0.0, "flops": 0.0}
         stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
         for _ in range(args.steps):
             _, _, info = ctx.image_processing(d_img, opt, out=d_out)
             kernel_ms.append(info["nystroem_kernel_ms"])
             mv["launches"] += info["matvecs"]
+            mv["narrow"] += info["narrow_sweeps"]
             mv["ms"] += info["matvec_ms"]
             mv["bytes"] += info["matvec_bytes"]
             rp["launches"] += info["nystroem_rowpass_launches"]
@@ -383,7 +384,9 @@ def main():
             pass
         sweeps = {"path": "grid-factored (L_A never stored)" if info["matvec_path"] == 1 else "stored L_A streamed (k_block_matvec_f16s)",
                   "launches_per_step": mvs["launches"] / args.steps, "avg_ms": round(mv_avg_ms, 4),
-                  "ms_per_step": round(mvs["ms"] / args.steps, 3)}
+                  "ms_per_step": round(mvs["ms"] / args.steps, 3),
+                  "narrow_per_step": mvs["narrow"] / args.steps,
+                  "narrow": "sweeps applied to the still-iterating columns only, packed into a block of 32 (block PCG)"}
         # (image row, value) pairs that occur in the image: the T rows the row pass has to deliver (the others are computed
         # by the 32-row MFMA tiles but never stored or read)
         present = float(np.mean([np.unique(img[r]).size for r in range(info["row0"], info["row1"])])) / 256.0
