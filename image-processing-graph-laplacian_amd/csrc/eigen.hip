@@ -1200,7 +1200,8 @@ __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double 
         // separate triangular inversion: u_k = v_k - sum_{j<k} c_jk u_j means T[:, k] = e_k - sum_{j<k} c_jk T[:, j], and
         // column j of T is final when step j begins -- the same rank-one update as the Schur complement's, with column j of
         // T broadcast through LDS beside column j of S (the inversion by back substitution was 40 of the kernel's 90 us).
-        __shared__ double colj[2][64], tcolj[2][64], gdiag[64];
+        __shared__ __attribute__((aligned(16))) double colj[2][64];
+        __shared__ double gdiag[64];
         const unsigned tx = t & 63, ty = t >> 6;
         if (t < 64) gdiag[t] = t < m ? G[(size_t)t * ld + t] : 0.0; // (a global load per step for the check below cost 1 us each)
         double a[16], tr[16], myq = 0.0;
@@ -1211,25 +1212,34 @@ __device__ void gsf_recur_body(double *S, unsigned ld, unsigned m, const double 
             tr[r] = k == tx ? 1.0 : 0.0;
         }
         __syncthreads();
+        // Column j travels as ONE vector: element k is S[k][j] for k > j (what the Schur update reads), T[k][j] for k < j and
+        // q_j at k = j -- a thread needs exactly one of the two per row -- stored wave by wave (k = ty + 4 r at ty * 16 + r),
+        // so that the four lanes owning the column write their 16 values as 8 ds_write_b128 instead of 32 single stores
+        // executed by whole waves (a third of a step).
         for (unsigned j = 0; j < m; ++j) {
-            double *cj = colj[j & 1], *tcj = tcolj[j & 1];
+            double *cj = colj[j & 1];
             if (tx == j) {
+                double v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    cj[ty + 4 * r] = a[r];
-                    tcj[ty + 4 * r] = tr[r];
+                    const unsigned k = ty + 4 * r;
+                    v[r] = k >= j ? a[r] : tr[r];
                 }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) *reinterpret_cast<double2 *>(&cj[ty * 16 + r]) = make_double2(v[r], v[r + 1]);
             }
-            __syncthreads(); // (the buffers written two steps ago are free: every thread passed the barrier of step j - 1 since)
-            const double qj = cj[j];
+            __syncthreads(); // (the buffer written two steps ago is free: every thread passed the barrier of step j - 1 since)
+            const double qj = cj[(j & 3) * 16 + (j >> 2)];
             if (tx == j) myq = qj;
             if (t == 0 && !(qj > GSF_COND_FLOOR * gdiag[j]) && gdiag[j] > 0.0) bad = 1;
-            const double cl = (qj != 0.0 && tx > j && tx < m) ? cj[tx] / qj : 0.0; // c_j,tx (0 for a zero vector, as the sweep does)
+            // c_j,tx (0 for a zero vector, as the sweep does); T[j][j] = 1 is not in the vector (the slot holds q_j)
+            const double cl = (qj != 0.0 && tx > j && tx < m) ? cj[(tx & 3) * 16 + (tx >> 2)] / qj : 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned k = ty + 4 * r;
-                if (k > j && k < m) a[r] -= cj[k] * cl; // S[k][l] -= <v_k,u_j> c_jl, k, l > j
-                if (k <= j) tr[r] -= tcj[k] * cl;       // T[:, l] -= c_jl T[:, j] (T[k][j] = 0 below the diagonal)
+                const double cv = k == j ? 1.0 : cj[ty * 16 + r];
+                if (k > j && k < m) a[r] -= cv * cl; // S[k][l] -= <v_k,u_j> c_jl, k, l > j
+                if (k <= j) tr[r] -= cv * cl;        // T[:, l] -= c_jl T[:, j] (T[k][j] = 0 below the diagonal, T[j][j] = 1)
             }
         }
         // Tn[j][k] = T[j][k] / |u_k| (upper triangular, zero elsewhere; a zero norm leaves the column unscaled), norms, flag
