@@ -1598,11 +1598,24 @@ __global__ __launch_bounds__(64) void k_gram(const float *__restrict__ X, const 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (unsigned i0 = r0; i0 < r1; i0 += 2) { // the two halves of the wave supply rows i0 and i0 + 1 (zeros past the last row:
-        const unsigned i = i0 + half;          // with an odd count the next row belongs to another rank's block)
-        const bool ok = i < r1;
-        const float a = ok ? X[(size_t)i * ld + 32 * ta + l31] : 0.f, b = ok ? Y[(size_t)i * ld + 32 * tb + l31] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    // The two halves of the wave supply rows i0 and i0 + 1 (zeros past the last row: with an odd count the next row belongs
+    // to another rank's block). The loads of 8 MFMAs are issued together, unconditionally (row index clamped, value zeroed
+    // afterwards): one conditional pair of loads per MFMA made the kernel a chain of 128 exposed memory latencies (45 us
+    // for 3 us of matrix work).
+    const float *xa = X + 32 * ta + l31, *yb = Y + 32 * tb + l31;
+    for (unsigned ib = r0; ib < r1; ib += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned i = min(ib + 2 * u + half, r1 - 1);
+            a[u] = xa[(size_t)i * ld];
+            b[u] = yb[(size_t)i * ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = ib + 2 * u + half < r1;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? a[u] : 0.f, ok ? b[u] : 0.f, acc, 0, 0, 0);
+        }
     }
     float *g = Gpart + (size_t)blockIdx.y * ld * ld;
 #pragma unroll

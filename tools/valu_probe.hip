@@ -14,6 +14,8 @@ __global__ void k_probe(float *out, long long *cycles, int iters)
     float r[16], a = threadIdx.x * 1e-3f + 1.f, b = 0.999f;
     for (int i = 0; i < 16; ++i) r[i] = i;
     f2 q[16], qa = {a, b}, qb = {b, a};
+    double d[16], da = a, db = b;
+    for (int i = 0; i < 16; ++i) d[i] = i;
     for (int i = 0; i < 16; ++i) q[i] = qa;
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
@@ -25,6 +27,8 @@ __global__ void k_probe(float *out, long long *cycles, int iters)
 #define MLH(i) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %2, %1, 0" : "+v"(r[i]) : "v"(a), "v"(b));
 #define PKM(i) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(q[i]) : "v"(qa), "v"(qb));
 #define FMA(i) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[i]) : "v"(a), "v"(b), "v"(a));
+#define F64(i) asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d[i]) : "v"(da), "v"(db), "v"(da));
+#define C64(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(a));
         if (OP == 0) { REP16(MUL) }
         if (OP == 1) { REP16(CVT) }
         if (OP == 2) { REP16(MIX) }
@@ -33,10 +37,12 @@ __global__ void k_probe(float *out, long long *cycles, int iters)
         if (OP == 5) { REP16(MLH) }
         if (OP == 6) { REP16(PKM) }
         if (OP == 7) { REP16(FMA) }
+        if (OP == 8) { REP16(F64) }
+        if (OP == 9) { REP16(C64) }
     }
     const long long t1 = __builtin_readcyclecounter();
     float s = 0;
-    for (int i = 0; i < 16; ++i) s += r[i] + q[i][0] + q[i][1];
+    for (int i = 0; i < 16; ++i) s += r[i] + q[i][0] + q[i][1] + (float)d[i];
     if (s == 123.456f) out[threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
 }
@@ -71,5 +77,7 @@ int main()
     run<4>("v_fma_mixhi_f16", 16, out, cyc);
     run<5>("v_fma_mixlo_f16 + mixhi same reg", 32, out, cyc);
     run<6>("v_pk_mul_f32", 16, out, cyc);
+    run<8>("v_fma_f64", 16, out, cyc);
+    run<9>("v_cvt_f64_f32", 16, out, cyc);
     return 0;
 }
