@@ -29,6 +29,8 @@ __global__ void k_probe(float *out, long long *cycles, int iters)
 #define FMA(i) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[i]) : "v"(a), "v"(b), "v"(a));
 #define F64(i) asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d[i]) : "v"(da), "v"(db), "v"(da));
 #define C64(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(a));
+#define A64(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[i]) : "v"(da), "v"(db));
+#define A32(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b));
         if (OP == 0) { REP16(MUL) }
         if (OP == 1) { REP16(CVT) }
         if (OP == 2) { REP16(MIX) }
@@ -39,6 +41,8 @@ __global__ void k_probe(float *out, long long *cycles, int iters)
         if (OP == 7) { REP16(FMA) }
         if (OP == 8) { REP16(F64) }
         if (OP == 9) { REP16(C64) }
+        if (OP == 10) { REP16(A64) }
+        if (OP == 11) { REP16(A32) }
     }
     const long long t1 = __builtin_readcyclecounter();
     float s = 0;
@@ -79,5 +83,7 @@ int main()
     run<6>("v_pk_mul_f32", 16, out, cyc);
     run<8>("v_fma_f64", 16, out, cyc);
     run<9>("v_cvt_f64_f32", 16, out, cyc);
+    run<10>("v_fma_f64, 16 accumulation chains", 16, out, cyc);
+    run<11>("v_fma_f32, 16 accumulation chains", 16, out, cyc);
     return 0;
 }
