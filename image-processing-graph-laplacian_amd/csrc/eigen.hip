@@ -1679,6 +1679,65 @@ __global__ __launch_bounds__(256) void k_resid(const float *__restrict__ X, cons
     block_col_reduce<1>(v, ld, partial, sh);
 }
 
+// The same partial sums for ld <= 64 on the f32 matrix pipe (exact f32 products, f32 accumulation like the vector form's FMA
+// chain): a workgroup takes RED_ROWS = 128 rows, wave w the 32 rows 32 w .. 32 w + 31 as the M tile of v_mfma_f32_32x32x2_f32,
+// K = the ld columns of X (lane half h takes a = (ld / 2) h + s at step s, so that a lane reads ld / 2 consecutive floats of its
+// row), N = 32-column tiles of G read from LDS. The vector form spent 67 us on 0.7 GFLOP at cfg4 (64 dependent FMAs per row
+// and thread, two barriers per four rows).
+template <int LD>
+__global__ __launch_bounds__(256) void k_resid_mfma(const float *__restrict__ X, const float *__restrict__ Y,
+                                                     const float *__restrict__ G, unsigned p, unsigned m, double *__restrict__ partial)
+{
+    constexpr int NTL = LD / 32, KH = LD / 2; // n-tiles; k-steps (two columns of X each)
+    __shared__ float Gs[LD * LD];
+    __shared__ double colsum[4][LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    for (unsigned e = threadIdx.x; e < LD * LD; e += 256) Gs[e] = G[e];
+    __syncthreads();
+    const unsigned row0 = blockIdx.x * RED_ROWS + 32 * wave, rowa = row0 + l31; // this lane's row as the A operand
+    float xa[KH];
+    {
+        const float *xr = X + (size_t)min(rowa, p - 1) * LD + KH * half;
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            const float4 v4 = reinterpret_cast<const float4 *>(xr)[q];
+            xa[4 * q] = v4.x, xa[4 * q + 1] = v4.y, xa[4 * q + 2] = v4.z, xa[4 * q + 3] = v4.w;
+        }
+        if (rowa >= p)
+#pragma unroll
+            for (int q = 0; q < KH; ++q) xa[q] = 0.f;
+    }
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int sk = 0; sk < KH; ++sk)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[sk], Gs[(KH * half + sk) * LD + 32 * nt + l31], acc[nt], 0, 0, 0);
+    // accumulator register r of a lane: row (r & 3) + 8 (r >> 2) + 4 half of the tile, column 32 nt + l31
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned i = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < p) {
+                const float sres = Y[(size_t)i * LD + 32 * nt + l31] - acc[nt][r];
+                v += (double)sres * (double)sres;
+            }
+        }
+        v += __shfl_xor(v, 32, 64); // the two halves hold different rows of the same column
+        if (half == 0) colsum[wave][32 * nt + l31] = 32 * nt + l31 < (int)m ? v : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < LD)
+        partial[(size_t)blockIdx.x * LD + threadIdx.x] =
+            (colsum[0][threadIdx.x] + colsum[1][threadIdx.x]) + (colsum[2][threadIdx.x] + colsum[3][threadIdx.x]);
+}
+
 struct ResWork {
     DevBuf<float> AX, Gpart, G;
     DevBuf<double> partial, sums;
@@ -1723,7 +1782,12 @@ static int residual_dev(glf_ctx *ctx, ResWork &w, const float *A, int64_t lda, u
     hipLaunchKernelGGL(k_gram_sum, dim3((ld * ld + 63) / 64), dim3(256), 0, st, w.Gpart.p, w.nchunks, ld, w.G.p);
     GLF_LAUNCH_CHECK(ctx);
     if (rows.dist) GLF_TRY(allreduce_f(ctx, w.G.p, (size_t)ld * ld));
-    if (nblk > 0) hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X + off, w.AX.p + off, w.G.p, nloc, ld, m, w.partial.p);
+    if (nblk > 0 && ld == 64)
+        hipLaunchKernelGGL(k_resid_mfma<64>, dim3(nblk), dim3(256), 0, st, X + off, w.AX.p + off, w.G.p, nloc, m, w.partial.p);
+    else if (nblk > 0 && ld == 32)
+        hipLaunchKernelGGL(k_resid_mfma<32>, dim3(nblk), dim3(256), 0, st, X + off, w.AX.p + off, w.G.p, nloc, m, w.partial.p);
+    else if (nblk > 0)
+        hipLaunchKernelGGL(k_resid, dim3(nblk), dim3(256), 0, st, X + off, w.AX.p + off, w.G.p, nloc, ld, m, w.partial.p);
     if (rows.dist) {
         hipLaunchKernelGGL(k_sum_partials_nv<1>, dim3(1), dim3(256), 0, st, w.partial.p, nblk, ld, w.sums.p);
         GLF_LAUNCH_CHECK(ctx);
