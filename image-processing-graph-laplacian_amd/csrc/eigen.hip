@@ -1445,6 +1445,54 @@ __global__ __launch_bounds__(256) void k_gsf_apply(float *__restrict__ X, unsign
         }
 }
 
+// The same product for ld <= 64 on the f64 matrix pipe: M = 16 rows of X, N = 16 columns k, K = the columns j in blocks of 16
+// (within a block lane group q = lane / 16 takes j = 16 jb + 4 q + s at step s, so a lane reads one float4 of its row per
+// block). Tn is upper triangular: column tile t needs the blocks jb <= t only (40 of the 64 MFMAs of a row tile). Tn sits in
+// LDS with rows of LD + 4 doubles (the two j rows a half-wave reads are 4 apart: 32 banks apart with that stride).
+// `tiles` row tiles per wave (1 .. 4: enough workgroups for every CU before a workgroup's copy of Tn is shared by more rows).
+template <int LD>
+__global__ __launch_bounds__(256) void k_gsf_apply_mfma(float *__restrict__ X, unsigned n, unsigned m, const double *__restrict__ Tn,
+                                                         const int *__restrict__ flag, int tiles)
+{
+    if (*flag) return; // ill-conditioned: the caller runs the sequential sweep on the untouched X
+    constexpr int NTL = LD / 16, TS = LD + 4;
+    __shared__ double ts[LD * TS];
+    for (unsigned e = threadIdx.x; e < LD * LD; e += 256) ts[(e / LD) * TS + e % LD] = Tn[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+#pragma unroll 1
+    for (int tile = 0; tile < tiles; ++tile) {
+        const unsigned row0 = (blockIdx.x * 4 * tiles + wave * tiles + tile) * 16;
+        if (row0 >= n) break; // (wave-uniform; no barrier below)
+        const unsigned ra = min(row0 + l15, n - 1); // this lane's row as the A operand (a row past the end repeats the last: not stored)
+        float4 xa[NTL];
+#pragma unroll
+        for (int jb = 0; jb < NTL; ++jb) xa[jb] = *reinterpret_cast<const float4 *>(X + (size_t)ra * LD + 16 * jb + 4 * lq);
+        f64x4 acc[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < NTL; ++jb) {
+            const double a4[4] = {(double)xa[jb].x, (double)xa[jb].y, (double)xa[jb].z, (double)xa[jb].w};
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+                for (int t = jb; t < NTL; ++t) // T[j][k] = 0 for j > k: the column tiles left of the block's diagonal get nothing
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[sk], ts[(16 * jb + 4 * lq + sk) * TS + 16 * t + l15], acc[t], 0, 0, 0);
+        }
+        // result register r of a lane: row lq + 4 r of the tile, column 16 t + l15
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned i = row0 + lq + 4 * r;
+                if (i < n && 16 * t + l15 < (int)m) X[(size_t)i * LD + 16 * t + l15] = (float)acc[t][r];
+            }
+    }
+}
+
 // Y[i][c] -= sum_a X[i][a] C[a][c] (f64 accumulation), a < ma: the projection of one block of vectors onto an earlier,
 // already orthonormal block (the cross-panel terms of classical Gram-Schmidt for more than 256 vectors, and X (X^T A X) of the
 // residual). Same tiling as k_gsf_apply.
@@ -1479,6 +1527,18 @@ __global__ __launch_bounds__(256) void k_gsf_sub(float *__restrict__ Y, const fl
         const unsigned i = r0 + rl + q * nrl;
         if (i < n) Y[(size_t)i * ld + col] = (float)((double)Y[(size_t)i * ld + col] - acc[q]);
     }
+}
+
+static void launch_gsf_apply(hipStream_t st, float *X, unsigned n, unsigned ld, unsigned m, const double *Tn, const int *flag)
+{
+    const int tiles = (int)std::max<int64_t>(1, std::min<int64_t>(4, ceil_div(n, 16 * 4 * 256)));
+    const unsigned rows_wg = 16 * 4 * (unsigned)tiles;
+    if (ld == 64)
+        hipLaunchKernelGGL(k_gsf_apply_mfma<64>, dim3((unsigned)ceil_div(n, rows_wg)), dim3(256), 0, st, X, n, m, Tn, flag, tiles);
+    else if (ld == 32)
+        hipLaunchKernelGGL(k_gsf_apply_mfma<32>, dim3((unsigned)ceil_div(n, rows_wg)), dim3(256), 0, st, X, n, m, Tn, flag, tiles);
+    else
+        hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, GSF_APPLY_TILE / ld)), dim3(256), 0, st, X, n, ld, m, Tn, flag);
 }
 
 struct GsFusedWork {
@@ -1550,7 +1610,7 @@ static int orthonormalise_fused_dev(glf_ctx *ctx, GsFusedWork &f, float *X, Rows
     else
         hipLaunchKernelGGL(k_gsf_recur_global, dim3(1), dim3(256), 0, st, ld, m, f.G.p, f.S.p, f.Tn.p, d_norms, f.flag.p, f.h_flag);
     if (n > 0)
-        hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(n, GSF_APPLY_TILE / ld)), dim3(256), 0, st, Xl, n, ld, m, f.Tn.p, f.flag.p);
+        launch_gsf_apply(st, Xl, n, ld, m, f.Tn.p, f.flag.p);
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(st));
     *fell_back = *(volatile int *)f.h_flag;
@@ -1970,9 +2030,7 @@ int inverse_power_iteration(glf_ctx *ctx, const float *A, int64_t lda, unsigned 
         if (it % opti_gs == 0) {
             GLF_TRY(orthonormalise_dev(ctx, gs, X.p, p, m, ld, rows, shard, &replicated)); // :174-177
             if (ax_ready && gs.last_fused) { // A X_new = (A Y) Tn
-                if (nloc)
-                    hipLaunchKernelGGL(k_gsf_apply, dim3((unsigned)ceil_div(nloc, GSF_APPLY_TILE / ld)), dim3(256), 0, st, rs.AX.p + off, nloc, ld,
-                                       m, gs.fused.Tn.p, gs.fused.flag.p);
+                if (nloc) launch_gsf_apply(st, rs.AX.p + off, nloc, ld, m, gs.fused.Tn.p, gs.fused.flag.p);
             } else {
                 ax_ready = false; // column-by-column sweep: no triangular map at hand
             }
