@@ -545,11 +545,13 @@ constexpr int RED_ROWS = 128; // rows per reduction workgroup (667 workgroups at
 // Second level of the column reductions, one 256-thread workgroup: out[v] (valid for t < ld) = sum over the nblk
 // blocks of partial[(b * NV + v) * ld + t % ld]. The 256 / ld thread rows take interleaved blocks and are combined
 // through LDS -- all in a fixed order.
-template <int NV>
+// NTHR: threads of the workgroup (256, or 1024 where the reduction sits between two sweeps of the solver: four times the
+// thread rows, a quarter of the dependent load batches).
+template <int NV, int NTHR = 256>
 __device__ __forceinline__ void wg_sum_partials(const double *__restrict__ partial, int nblk, unsigned ld, double (&out)[NV],
-                                                double *sh /* [NV][256] */)
+                                                double *sh /* [NV][NTHR] */)
 {
-    const int t = threadIdx.x, col = t % ld, part = t / ld, nparts = 256 / ld;
+    const int t = threadIdx.x, col = t % ld, part = t / ld, nparts = NTHR / ld;
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
@@ -571,13 +573,13 @@ __device__ __forceinline__ void wg_sum_partials(const double *__restrict__ parti
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] += partial[((size_t)b * NV + v) * ld + col];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) sh[v * 256 + t] = acc[v];
+    for (int v = 0; v < NV; ++v) sh[v * NTHR + t] = acc[v];
     __syncthreads();
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         double s = 0.0;
         if (t < (int)ld)
-            for (int r = 0; r < nparts; ++r) s += sh[v * 256 + r * ld + col];
+            for (int r = 0; r < nparts; ++r) s += sh[v * NTHR + r * ld + col];
         out[v] = s;
     }
     __syncthreads();
@@ -707,12 +709,12 @@ __global__ __launch_bounds__(256) void k_cg_dot(const float *__restrict__ P, con
     block_col_reduce<1>(v, ld, partial, sh);
 }
 
-__global__ __launch_bounds__(256) void k_cg_alpha(const double *__restrict__ partial, int nblk, unsigned ld, CgScalars s)
+__global__ __launch_bounds__(1024) void k_cg_alpha(const double *__restrict__ partial, int nblk, unsigned ld, CgScalars s)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[1024];
     const int c = threadIdx.x;
     double pap[1];
-    wg_sum_partials<1>(partial, nblk, ld, pap, sh);
+    wg_sum_partials<1, 1024>(partial, nblk, ld, pap, sh);
     if (c < (int)ld) s.alpha[c] = s.active[c] ? s.rz[c] / pap[0] : 0.0;
 }
 
@@ -743,13 +745,13 @@ __global__ __launch_bounds__(256) void k_cg_update(float *__restrict__ Xs, float
     block_col_reduce<2>(v, ld, partial, sh);
 }
 
-__global__ __launch_bounds__(256) void k_cg_beta(const double *__restrict__ partial, int nblk, unsigned ld, double rtol2,
-                                                  CgScalars s)
+__global__ __launch_bounds__(1024) void k_cg_beta(const double *__restrict__ partial, int nblk, unsigned ld, double rtol2,
+                                                   CgScalars s)
 {
-    __shared__ double sh[2 * 256];
+    __shared__ double sh[2 * 1024];
     const int c = threadIdx.x;
     double tot[2];
-    wg_sum_partials<2>(partial, nblk, ld, tot, sh);
+    wg_sum_partials<2, 1024>(partial, nblk, ld, tot, sh);
     if (c < (int)ld && s.active[c]) {
         const double rr = tot[0], rz = tot[1];
         if (rr <= rtol2 * s.bn2[c]) { // ||r|| <= rtol ||b||
@@ -927,12 +929,12 @@ static int block_pcg_work(glf_ctx *ctx, CgWork &w, const float *A, int64_t lda, 
         }
         if (nblk > 0) hipLaunchKernelGGL(k_cg_dot, dim3(nblk), dim3(256), 0, st, w.P.p + off, w.AP.p + off, nloc, ld, w.partial.p);
         GLF_TRY(reduce2(1, &src, &src_blk));
-        hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(256), 0, st, src, src_blk, ld, w.s);
+        hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(1024), 0, st, src, src_blk, ld, w.s);
         if (nblk > 0)
             hipLaunchKernelGGL(k_cg_update, dim3(nblk), dim3(256), 0, st, w.Xs.p + off, w.R.p + off, w.P.p + off, w.AP.p + off,
                                w.dinv.p + rows.r0, nloc, ld, w.s, w.partial.p);
         GLF_TRY(reduce2(2, &src, &src_blk));
-        hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(256), 0, st, src, src_blk, ld, rtol * rtol, w.s);
+        hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1024), 0, st, src, src_blk, ld, rtol * rtol, w.s);
         if (nelem_blocks > 0)
             hipLaunchKernelGGL(k_cg_pupdate, dim3(nelem_blocks), dim3(256), 0, st, w.P.p + off, w.R.p + off, w.dinv.p + rows.r0, nloc, ld, w.s);
         GLF_LAUNCH_CHECK(ctx);
