@@ -752,6 +752,7 @@ __global__ __launch_bounds__(1024) void k_cg_beta(const double *__restrict__ par
     const int c = threadIdx.x;
     double tot[2];
     wg_sum_partials<2, 1024>(partial, nblk, ld, tot, sh);
+    int still = 0; // this thread's column keeps iterating
     if (c < (int)ld && s.active[c]) {
         const double rr = tot[0], rz = tot[1];
         if (rr <= rtol2 * s.bn2[c]) { // ||r|| <= rtol ||b||
@@ -760,14 +761,11 @@ __global__ __launch_bounds__(1024) void k_cg_beta(const double *__restrict__ par
         } else {
             s.beta[c] = rz / s.rz[c];
             s.rz[c] = rz;
+            still = 1;
         }
     }
-    __syncthreads();
-    if (c == 0) {
-        int n = 0;
-        for (unsigned k = 0; k < ld; ++k) n += s.active[k];
-        *s.nactive = n;
-    }
+    const int n = __syncthreads_count(still); // (one thread re-reading the ld flags from memory took a third of the kernel)
+    if (c == 0) *s.nactive = n;
 }
 
 // p = dinv r + beta p
