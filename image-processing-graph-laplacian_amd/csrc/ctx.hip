@@ -92,11 +92,12 @@ int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value)
     auto flag = [&]() { return !unset && !is("0"); };
     glf_tuning &t = ctx->tune;
     if (!std::strcmp(key, "NYS_PATH") || !std::strcmp(key, "DEG_PATH")) {
-        if (!unset && !is("grid") && !is("direct")) return GLF_ERR_INVALID;
-        (key[0] == 'N' ? t.nys_path : t.deg_path) = unset ? 0 : is("grid") ? 1 : 2;
+        const bool nys = key[0] == 'N';
+        if (!unset && !is("grid") && !is("direct") && !(nys && is("rank"))) return GLF_ERR_INVALID;
+        (nys ? t.nys_path : t.deg_path) = unset ? 0 : is("grid") ? 1 : is("rank") ? 3 : 2;
     } else if (!std::strcmp(key, "MV_PATH")) {
-        if (!unset && !is("grid") && !is("dense")) return GLF_ERR_INVALID;
-        t.mv_path = unset ? 0 : is("grid") ? 1 : 2;
+        if (!unset && !is("grid") && !is("dense") && !is("rank")) return GLF_ERR_INVALID;
+        t.mv_path = unset ? 0 : is("grid") ? 1 : is("rank") ? 3 : 2;
     } else if (!std::strcmp(key, "ROWPASS")) {
         if (!unset && !is("rt") && !is("v1")) return GLF_ERR_INVALID;
         t.rowpass = is("v1") ? 1 : 0;
@@ -145,6 +146,8 @@ int glf_ctx_destroy(glf_ctx *ctx)
     glf::native_comm_release(ctx);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->x0_block) (void)hipFree(ctx->x0_block);
+    if (ctx->rank_ftab) (void)hipFree(ctx->rank_ftab);
+    if (ctx->rank_ff) (void)hipFree(ctx->rank_ff);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     glf::pool_free_all(ctx, false);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -27,9 +27,9 @@ struct glf_pool_block {
 // computes the same sums and is tested against the oracle and against the others. Set with glf_ctx_set_tuning, initialised at
 // context creation from the environment variables GLF_<KEY> (read once, never per call).
 struct glf_tuning {
-    int nys_path = 0;            // NYS_PATH: 0 auto, 1 grid (factored Nystroem), 2 direct (entry by entry)
+    int nys_path = 0;            // NYS_PATH: 0 auto, 1 grid (factored Nystroem, all 256 grey levels), 2 direct (entry by entry), 3 rank (factored, photometric table as a rank-R expansion)
     int deg_path = 0;            // DEG_PATH: likewise for the degree
-    int mv_path = 0;             // MV_PATH: 0 auto, 1 grid (L_A applied in factored form), 2 dense (stored L_A)
+    int mv_path = 0;             // MV_PATH: 0 auto, 1 grid (L_A applied in factored form), 2 dense (stored L_A), 3 rank (factored, rank-R photometric table)
     int rowpass = 0;             // ROWPASS: row pass of the Nystroem passes: 0 / rt = row-tile form, 1 / v1 = one image row per wave
     int rowpass_op = 0;          // ROWPASS_OP: row pass of the L_A sweeps: 0 / v1, 1 / rt
     bool nys_no_lut = false;     // NYS_NO_LUT: direct Nystroem kernel generates entries with v_exp_f32 instead of LDS tables
@@ -74,6 +74,12 @@ struct glf_ctx {
     // one page of pinned, device-visible host memory the eigensolver's kernels write their flags and norms into (read
     // after a stream synchronise; no D2H copy launches, and no hipHostMalloc per image): see glf::ctx_pinned()
     void *pinned = nullptr;
+    // rank form of the grid-factored contractions (nystroem_rank.inc): the factor F of the photometric table for one scale
+    bool rank_valid = false;
+    float rank_s_val = 0.f;
+    int rank_R = 0;             // terms of the expansion (0: the table is not low-rank enough, the exact form runs)
+    void *rank_ftab = nullptr;  // f32 [R][256]
+    void *rank_ff = nullptr;    // split-f16 A fragments of 2^15 F
     // debug pool (GLF_POOL_DEBUG=1): exact-size blocks + guard zone, NaN-filled floating-point buffers, no reuse
     bool pool_debug = false;
     int pool_violations = 0;
@@ -198,6 +204,9 @@ struct KernelCoef {
     int kernel;  // GLF_KERNEL_*: NLM takes its own kernels (nlm.hip), the others share the positional ones
 };
 KernelCoef make_coef(int kernel, float h_loc, float h_val);
+// host_util.cpp: P[v][w] = exp2(-s_val (v - w)^2) ~= F F^T in f64, F [256][rank] (strongest term first)
+bool photometric_factor(double s_val, int max_chol, std::vector<double> &F, int &rank_out);
+double photometric_factor_error(double s_val, const std::vector<double> &F, int rank, int R);
 
 __device__ __forceinline__ float kernel_eval(float dr, float dc, float dv, float s_loc, float s_val)
 {
@@ -307,6 +316,7 @@ int grid_op_create(glf_ctx *ctx, const float4 *d_samples, const unsigned *h_idx,
                    KernelCoef coef, GridOp **out); // GLF_ERR_UNSUPPORTED: not a tensor grid (or not the split-f16 mode)
 void grid_op_destroy(GridOp *op);
 unsigned grid_op_rows_per_rank(const GridOp *op, int size); // all-gather block: whole grid rows
+int grid_op_path(const GridOp *op);                          // glf_stats.matvec_path: 1 exact grid form, 3 rank form
 int grid_op_apply(glf_ctx *ctx, GridOp *op, const float *X, float *Y, unsigned ld, double alpha, const double *d_degree,
                   unsigned row0, unsigned row1, int window);
 

@@ -1,8 +1,10 @@
 // host_util.cpp -- host-side stages of the C-ABI: sampling grid, X0 random block,
 // synthetic benchmark images. No device code.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <vector>
 
 #include "../../include/glf.h"
 
@@ -117,3 +119,118 @@ int glf_synth_image(uint8_t *out, int width, int height, uint64_t seed)
 }
 
 } // extern "C"
+
+// ---- low-rank factor of the photometric table -----------------------------------------------------------------
+// P[v][w] = exp2(-s_val (v - w)^2) over the 256 grey levels (the photometric factor of hpc/affinity.c:59-113 with
+// s_val = log2(e) / h_val^2) is symmetric positive semi-definite with a rapidly decaying spectrum: at the reference's
+// h_val = 30 its rank-32 eigen-expansion P ~= F F^T reproduces every entry to 1.5e-11. The factor is what the "rank"
+// form of the grid-factored contractions carries instead of the 256 grey levels (nystroem_rank.inc).
+// Computed in f64: pivoted Cholesky P ~= L L^T down to a residual diagonal of 1e-15 (r <= max_chol columns), then the
+// eigen-decomposition of the small r x r matrix L^T L = Q diag(lambda) Q^T by cyclic Jacobi; F = L Q has the columns
+// sqrt(lambda_k) u_k of the eigen-expansion, strongest first. Rows of F have sum_k F[v][k]^2 <= P[v][v] = 1.
+namespace glf {
+
+// F: [256][rank_out] row-major. Returns false when more than max_chol Cholesky columns are needed (sharp kernels).
+bool photometric_factor(double s_val, int max_chol, std::vector<double> &F, int &rank_out)
+{
+    constexpr int n = 256;
+    std::vector<double> L((size_t)n * max_chol, 0.0), d(n, 1.0);
+    auto P = [&](int v, int w) { return std::exp2(-s_val * (double)(v - w) * (double)(v - w)); };
+    int r = 0;
+    for (; r < max_chol; ++r) {
+        int piv = 0;
+        for (int v = 1; v < n; ++v)
+            if (d[v] > d[piv]) piv = v;
+        if (d[piv] <= 1e-15) break;
+        const double inv = 1.0 / std::sqrt(d[piv]);
+        for (int v = 0; v < n; ++v) {
+            double x = P(v, piv);
+            for (int k = 0; k < r; ++k) x -= L[(size_t)v * max_chol + k] * L[(size_t)piv * max_chol + k];
+            x *= inv;
+            L[(size_t)v * max_chol + r] = x;
+            d[v] -= x * x;
+        }
+        d[piv] = 0.0;
+    }
+    if (r == max_chol) {
+        double worst = 0.0;
+        for (int v = 0; v < n; ++v) worst = std::max(worst, d[v]);
+        if (worst > 1e-15) return false;
+    }
+    // G = L^T L (r x r), Jacobi eigen-decomposition G = Q diag(lam) Q^T
+    std::vector<double> G((size_t)r * r, 0.0), Q((size_t)r * r, 0.0);
+    for (int i = 0; i < r; ++i)
+        for (int j = i; j < r; ++j) {
+            double x = 0.0;
+            for (int v = 0; v < n; ++v) x += L[(size_t)v * max_chol + i] * L[(size_t)v * max_chol + j];
+            G[(size_t)i * r + j] = G[(size_t)j * r + i] = x;
+        }
+    for (int i = 0; i < r; ++i) Q[(size_t)i * r + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < r; ++i) {
+            diag += G[(size_t)i * r + i] * G[(size_t)i * r + i];
+            for (int j = i + 1; j < r; ++j) off += G[(size_t)i * r + j] * G[(size_t)i * r + j];
+        }
+        if (off <= 1e-32 * diag) break;
+        for (int pI = 0; pI < r - 1; ++pI)
+            for (int q = pI + 1; q < r; ++q) {
+                const double apq = G[(size_t)pI * r + q];
+                if (apq == 0.0) continue;
+                const double app = G[(size_t)pI * r + pI], aqq = G[(size_t)q * r + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < r; ++k) { // columns p, q
+                    const double gkp = G[(size_t)k * r + pI], gkq = G[(size_t)k * r + q];
+                    G[(size_t)k * r + pI] = c * gkp - s * gkq;
+                    G[(size_t)k * r + q] = s * gkp + c * gkq;
+                }
+                for (int k = 0; k < r; ++k) { // rows p, q
+                    const double gpk = G[(size_t)pI * r + k], gqk = G[(size_t)q * r + k];
+                    G[(size_t)pI * r + k] = c * gpk - s * gqk;
+                    G[(size_t)q * r + k] = s * gpk + c * gqk;
+                }
+                for (int k = 0; k < r; ++k) {
+                    const double qkp = Q[(size_t)k * r + pI], qkq = Q[(size_t)k * r + q];
+                    Q[(size_t)k * r + pI] = c * qkp - s * qkq;
+                    Q[(size_t)k * r + q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    std::vector<int> order(r);
+    for (int i = 0; i < r; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return G[(size_t)a * r + a] > G[(size_t)b * r + b]; });
+    F.assign((size_t)n * r, 0.0);
+    for (int k = 0; k < r; ++k) {
+        const int col = order[k];
+        // sign convention: the entry of largest magnitude of every column is positive (the product F F^T does not care)
+        double big = 0.0;
+        for (int v = 0; v < n; ++v) {
+            double x = 0.0;
+            for (int j = 0; j < r; ++j) x += L[(size_t)v * max_chol + j] * Q[(size_t)j * r + col];
+            F[(size_t)v * r + k] = x;
+            if (std::fabs(x) > std::fabs(big)) big = x;
+        }
+        if (big < 0.0)
+            for (int v = 0; v < n; ++v) F[(size_t)v * r + k] = -F[(size_t)v * r + k];
+    }
+    rank_out = r;
+    return true;
+}
+
+// max over (v, w) of |sum_{k < R} F[v][k] F[w][k] - P[v][w]|
+double photometric_factor_error(double s_val, const std::vector<double> &F, int rank, int R)
+{
+    constexpr int n = 256;
+    double worst = 0.0;
+    for (int v = 0; v < n; ++v)
+        for (int w = v; w < n; ++w) {
+            double x = 0.0;
+            for (int k = 0; k < R && k < rank; ++k) x += F[(size_t)v * rank + k] * F[(size_t)w * rank + k];
+            worst = std::max(worst, std::fabs(x - std::exp2(-s_val * (double)(v - w) * (double)(v - w))));
+        }
+    return worst;
+}
+
+} // namespace glf

@@ -815,11 +815,9 @@ int nystroem_contract(glf_ctx *ctx, const uint8_t *d_img, int width, int height,
     {
         // a tensor-grid sample set (hpc/sampling.c always yields one) takes the factored contraction
         const int rc = nystroem_contract_grid(ctx, d_img, width, height, pix0, pix1, d_samples, d_mask, d_idx, p, coef, d_psi, ld,
-                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, mfma_flops, rowpass);
-        if (rc != GLF_ERR_UNSUPPORTED) {
-            if (path) *path = 1;
-            return rc;
-        }
+                                              d_phi, raster, d_c, kernel_ms, window, entries_evaluated, mfma_flops, rowpass, path);
+        if (rc != GLF_ERR_UNSUPPORTED) return rc;
+        if (path) *path = 0;
     }
     int rc = GLF_ERR_UNSUPPORTED;
     if (ctx->contraction == GLF_CONTRACT_F16_SPLIT) {

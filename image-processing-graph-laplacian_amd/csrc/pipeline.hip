@@ -560,13 +560,13 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         ~GridOpGuard() { grid_op_destroy(op); }
     } gop;
     {
-        const bool want = ctx->tune.mv_path == 1 ? true : ctx->tune.mv_path == 2 ? false : p >= 16384;
+        const bool want = (ctx->tune.mv_path == 1 || ctx->tune.mv_path == 3) ? true : ctx->tune.mv_path == 2 ? false : p >= 16384;
         if (want && opt.kernel != GLF_KERNEL_NLM) {
             const int rc = grid_op_create(ctx, tb.samples.p, h_idx, p, width, height, coef, &gop.op);
             if (rc != GLF_OK && rc != GLF_ERR_UNSUPPORTED) return rc;
         }
     }
-    S.matvec_path = gop.op ? 1 : 0;
+    S.matvec_path = gop.op ? grid_op_path(gop.op) : 0;
     if (gop.op) {
         shard.grid = gop.op;
         shard.grid_alpha = alpha;

@@ -317,8 +317,9 @@ typedef struct glf_stats {
     double nystroem_evaluated, degree_evaluated;
     /* f16 MFMA flops issued by the Nystroem contraction (3 products per split multiply-add) */
     double nystroem_mfma_flops;
-    int32_t nystroem_path;  /* 0 direct kernel (K_B generated entry by entry), 1 grid-factored */
-    int32_t matvec_path;    /* 0 stored L_A streamed per sweep, 1 L_A applied in grid-factored form (never stored) */
+    int32_t nystroem_path;  /* 0 direct kernel (K_B generated entry by entry), 1 grid-factored (all 256 grey levels),
+                               3 grid-factored in rank form (photometric table as a rank-R expansion) */
+    int32_t matvec_path;    /* 0 stored L_A streamed per sweep, 1 L_A applied in grid-factored form (never stored), 3 the same in rank form */
     /* grid-factored Nystroem: the row-pass kernel (k_grid_rowpass) alone -- launches, summed device ms (HIP events around
      * each launch) and its algorithmic flops 2 rows 256 nc nr ld (one product per multiply-add) */
     int32_t nystroem_rowpass_launches;

@@ -247,6 +247,7 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
     Pi_inv = ctx.InverseDiagMat(Pi)
     got = {}
     for mode, tune in (("grid", {"NYS_PATH": "grid"}), ("grid_v1", {"NYS_PATH": "grid", "ROWPASS": "v1"}),
+                       ("rank", {"NYS_PATH": "rank"}),
                        ("lut", {"NYS_PATH": "direct"}), ("exp", {"NYS_PATH": "direct", "NYS_NO_LUT": "1"})):
         ctx.set_tuning(NYS_PATH=None, NYS_NO_LUT=None, ROWPASS=None)
         ctx.set_tuning(**tune)
@@ -259,6 +260,8 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
         np.testing.assert_allclose(got[mode], ref, rtol=0, atol=PHI_TOL * scale, err_msg=mode)
     np.testing.assert_allclose(got["lut"], got["exp"], rtol=0, atol=2e-5 * scale)
     np.testing.assert_allclose(got["grid"], got["exp"], rtol=0, atol=2e-5 * scale)
+    # rank form: the photometric table as its rank-R eigen-expansion (max |F F^T - P| <= 2^-30), T' formed in LDS
+    np.testing.assert_allclose(got["rank"], got["exp"], rtol=0, atol=2e-5 * scale)
     # the two row-pass kernels (row-tile form: Er as the A operand; v1: one image row per wave) split different operands
     np.testing.assert_allclose(got["grid"], got["grid_v1"], rtol=0, atol=2e-5 * scale)
     ctx.destroy(L_A, phi_A, Pi, Pi_inv, K_B)
@@ -415,6 +418,20 @@ def test_call_sequence_of_the_recorded_fault(golden, png, mode, pool, monkeypatc
 
 
 _FAULT_SEQ = {}
+
+
+@pytest.mark.parametrize("name,ns,m,eps", [("ragged", 20, 5, 0.1), ("cat50", 50, 53, 0.1), ("test", 100, 16, 0.1), ("test", 400, 70, 0.1)])
+def test_end_to_end_with_rank_forms_forced(ctx, golden, png, name, ns, m, eps):
+    """The rank form of the grid-factored contractions (photometric table as a rank-R expansion, T' formed in LDS: the
+    default from 1024-pixel-wide images on) forced on the small reference images, for the Nystroem extension and for the
+    L_A sweeps of the eigen-solve, against the fp64 oracle."""
+    ctx.set_tuning(NYS_PATH="rank", DEG_PATH="grid", MV_PATH="rank")
+    img, _ = _images(golden, png)[name]
+    out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
+                                         want_float=True)
+    if info["contraction"] == glf.CONTRACT_F16_SPLIT:
+        assert info["nystroem_path"] == 3 and info["matvec_path"] == 3
+    _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info)
 
 
 @pytest.mark.parametrize("rowpass", ["default", "v1", "rt"])
