@@ -93,8 +93,8 @@ constexpr int VEC_PAD = 64; // rows of vector blocks / lda of L_A are padded to 
 constexpr int NYS_PAD = 64; // sample table and Psi are zero-padded to a multiple of this many rows
 
 // pinned page layout (bytes): [0] PCG active-column counter (int), [64] Gram-Schmidt fallback flag (int),
-// [128 .. 128 + 8 * 256) residual column sums (double[ld <= 256])
-constexpr size_t PINNED_BYTES = 4096, PINNED_NACTIVE = 0, PINNED_GSFLAG = 64, PINNED_SUMS = 128;
+// [128 .. 128 + 8 * 256) residual column sums (double[ld <= 256]), [3072] largest segment count of a row (rank form)
+constexpr size_t PINNED_BYTES = 4096, PINNED_NACTIVE = 0, PINNED_GSFLAG = 64, PINNED_SUMS = 128, PINNED_RANKSEG = 3072;
 inline char *ctx_pinned(glf_ctx *ctx)
 {
     if (!ctx->pinned && hipHostMalloc(&ctx->pinned, PINNED_BYTES, hipHostMallocDefault) != hipSuccess) ctx->pinned = nullptr;

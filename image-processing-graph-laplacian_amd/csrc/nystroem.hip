@@ -361,6 +361,7 @@ static int launch_nystroem(glf_ctx *ctx, const uint8_t *d_img, int width, int64_
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float NYS_F16_KSCALE_LOG2 = 15.0f; // K' = 2^15 K  (max 32768 < 65504)
 
@@ -918,3 +919,10 @@ int permute_rows(glf_ctx *ctx, const float *d_in, float *d_out, int64_t N, unsig
 }
 
 } // namespace glf
+
+#ifdef RK_STAMP
+extern "C" int glf_debug_rank_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(glf::g_rk_stamps), sizeof(unsigned long long) * 8 * 256) == hipSuccess ? 0 : -1;
+}
+#endif
