@@ -75,9 +75,15 @@ def _residual_fp64(torch, LA, p, X):
     return float(torch.linalg.norm(R)), torch.linalg.eigvalsh(0.5 * (G + G.T)).cpu().numpy()
 
 
-@pytest.mark.parametrize("size", [2048, 4096])
-def test_headline_config_sampled_parity(ctx, size):
+@pytest.mark.parametrize("size,form", [(2048, "rank"), (2048, "grid"), (4096, "rank"), (4096, "grid")])
+def test_headline_config_sampled_parity(ctx, size, form):
+    """form: "rank" = the default kernels (grid-factored contractions with the photometric table as a rank-R expansion, T'
+    formed in LDS: what bench.py's headline times), "grid" = the same contractions carrying all 256 grey levels through
+    HBM (GLF_NYS_PATH / GLF_MV_PATH = grid: bench.py's second leg)."""
     torch = ctx.torch
+    ctx.reset_tuning()
+    if form == "grid":
+        ctx.set_tuning(NYS_PATH="grid", MV_PATH="grid")
     img = glf.synth_image(size, size, seed=0)
     assert zlib.crc32(img.tobytes()) == SYNTH_CRC32[size]
     N, m, eps = size * size, 64, 0.1
@@ -88,12 +94,14 @@ def test_headline_config_sampled_parity(ctx, size):
     d_img = ctx.to_device(img)
     opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
     out, zf, info = ctx.image_processing(d_img, opt, want_float=True, capture=True)
+    ctx.reset_tuning()
     cap = info["capture"]
     # the kernel families bench.py times
-    assert info["nystroem_path"] == 1 and info["matvec_path"] == 1 and info["contraction"] == glf.CONTRACT_F16_SPLIT
+    want_path = 3 if form == "rank" else 1
+    assert info["nystroem_path"] == want_path and info["matvec_path"] == want_path and info["contraction"] == glf.CONTRACT_F16_SPLIT
     assert (info["p"], info["m"], cap["ld"]) == (p, m, 64)
     assert torch.isfinite(zf).all() and info["residual"] <= eps
-    report = {"size": size, "p": p, "m": m, "outer_its": info["outer_its"], "inner_its_total": info["inner_its_total"],
+    report = {"size": size, "form": form, "p": p, "m": m, "outer_its": info["outer_its"], "inner_its_total": info["inner_its_total"],
               "residual": info["residual"], "ms_total": info["ms_total"]}
 
     # ---- degree on a sub-sample of the samples, alpha -----------------------------------------------------------------
@@ -151,7 +159,7 @@ def test_headline_config_sampled_parity(ctx, size):
                             out_gpu=lambda r: out[r].cpu().numpy(), gain=3.0, corr_gpu=lambda r: cap["corr"].view(size, size)[r].cpu().numpy())
     report["rows_check"] = res
     report["eigvals_min_max"] = [float(lam.min()), float(lam.max())]
-    _record("large_parity_%d.json" % size, report)
+    _record("large_parity_%d%s.json" % (size, "" if form == "rank" else "_grid"), report)
     print(json.dumps(report, default=float))
     assert res["phi_max_abs_err_over_max"] <= PHI_TOL
     assert res["rel_l2_correction"] <= CORR_TOL                       # the correction term z - y itself
@@ -171,7 +179,7 @@ def test_headline_config_sampled_parity(ctx, size):
     out_all = torch.clamp(torch.floor(z_all), 0.0, 255.0).to(torch.uint8)        # trunc(z) for z >= 0, 0 below (Q4)
     mism = float((out_all.reshape(size, size) != out).double().mean())
     report["u8_mismatch_frac_all_pixels"] = mism
-    _record("large_parity_%d.json" % size, report)
+    _record("large_parity_%d%s.json" % (size, "" if form == "rank" else "_grid"), report)
     assert mism <= 1e-4, mism               # only where the f32 / f64 corrections straddle an integer
 
 
@@ -185,8 +193,8 @@ HDR_KERNELS = [
 
 @pytest.mark.parametrize("size", [1024, 2048])
 def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
-    """Phi and z - y from (a) the default grid-factored split-f16 contraction, (b) the entry-by-entry split-f16 kernel and
-    (c) the exact-f32-operand MFMA kernel, each against the fp64 oracle on sampled rows; same Phi_A / eigenvalues for all
+    """Phi and z - y from (a) the default contraction (grid-factored, rank form), (a') the grid-factored form carrying all 256
+    grey levels, (b) the entry-by-entry split-f16 kernel and (c) the exact-f32-operand MFMA kernel, each against the fp64 oracle on sampled rows; same Phi_A / eigenvalues for all
     three (one eigen-solve)."""
     torch = ctx.torch
     img = glf.synth_image(size, size, seed=0)
@@ -211,9 +219,10 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
         phi_A = ctx.mat_to_numpy(vecs)
         Pi_inv = ctx.InverseDiagMat(vals)
         got = {}
-        for mode in ("grid_f16s", "direct_f16s", "direct_f32"):
+        for mode in ("rank_f16s", "grid_f16s", "direct_f16s", "direct_f32"):
             ctx.set_contraction(glf.CONTRACT_F32_MFMA if mode == "direct_f32" else glf.CONTRACT_F16_SPLIT)
-            ctx.set_tuning(NYS_PATH="grid" if mode == "grid_f16s" else "direct")
+            # (rank: h_val = 5 needs more than 64 terms for 2^-30 -- that kernel falls back to the exact grid form, by design)
+            ctx.set_tuning(NYS_PATH={"rank_f16s": "rank", "grid_f16s": "grid"}.get(mode, "direct"))
             phi_sf = ctx.Nystroem(L_B, vecs, Pi_inv)
             phi = ctx.Permutation(phi_sf, idx)
             ctx.destroy(phi_sf)
@@ -240,7 +249,7 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
         # the split-f16 results against the exact-f32-operand kernel directly (same rows): the 22-bit operands cost less
         # than the fp32 accumulation already does
         ref32 = got["direct_f32"][0].double()
-        for mode in ("grid_f16s", "direct_f16s"):
+        for mode in ("rank_f16s", "grid_f16s", "direct_f16s"):
             d = float((got[mode][0].double() - ref32).abs().max() / ref32.abs().max())
             report[key][mode + "_vs_f32_max_abs_over_max"] = d
             assert d <= PHI_TOL, (key, mode, d)
@@ -250,8 +259,9 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mv", ["rank", "grid"])
 @pytest.mark.parametrize("size,m", [(1024, 64), (1024, 100)])
-def test_narrow_sweeps_return_the_same_numbers(size, m):
+def test_narrow_sweeps_return_the_same_numbers(size, m, mv):
     """Block PCG applies the operator to the still-iterating columns only once few are left (packed into a block of 32
     columns, or of a multiple of 64 below ld): the operator's columns are independent, so eigenvalues and the filtered image
     must come out bit for bit as with full-width sweeps (GLF_NO_NARROW), and the narrow sweeps must actually occur."""
@@ -260,7 +270,7 @@ def test_narrow_sweeps_return_the_same_numbers(size, m):
     for narrow in (True, False):
         c = glf.Context(0)
         try:
-            c.set_tuning(NO_NARROW="0" if narrow else "1", MV_PATH="grid")
+            c.set_tuning(NO_NARROW="0" if narrow else "1", MV_PATH=mv)
             opt = glf.default_options(num_samples=int(size * size * 0.005), num_eigvals=m, epsilon=0.05)
             out, zf, info = c.image_processing(c.to_device(img), opt, want_float=True)
             res[narrow] = (out.cpu().numpy(), zf.cpu().numpy(), info)
