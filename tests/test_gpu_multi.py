@@ -39,12 +39,17 @@ def _check(img, opt, n, backend, devices):
     return infos
 
 
-@pytest.mark.parametrize("n", [1, 2, 3])
-@pytest.mark.parametrize("paths", ["direct", "grid"])
-def test_loopback_ranks_on_one_device_match_single_context(n, paths, monkeypatch):
+def _env_paths(monkeypatch, paths):
+    """direct: entry-by-entry kernels, stored L_A; grid / rank: the grid-factored forms (rank: the default at benchmark sizes)"""
     monkeypatch.setenv("GLF_NYS_PATH", paths)
-    monkeypatch.setenv("GLF_DEG_PATH", paths)
-    monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    monkeypatch.setenv("GLF_DEG_PATH", "direct" if paths == "direct" else "grid")
+    monkeypatch.setenv("GLF_MV_PATH", {"direct": "dense", "grid": "grid", "rank": "rank"}[paths])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
+def test_loopback_ranks_on_one_device_match_single_context(n, paths, monkeypatch):
+    _env_paths(monkeypatch, paths)
     img = glf.synth_image(96, 80, seed=4)
     opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
     _check(img, opt, n, glf.MULTI_LOOPBACK, [0] * n)
@@ -55,10 +60,8 @@ def test_loopback_more_ranks_than_grid_rows_and_odd_shards(monkeypatch):
     eigen-solve; image row shards of 7 or 8 rows) in both kernel families."""
     img = glf.synth_image(53, 37, seed=3)
     opt = glf.default_options(num_samples=20, num_eigvals=5, epsilon=0.1)
-    for paths in ("direct", "grid"):
-        monkeypatch.setenv("GLF_NYS_PATH", paths)
-        monkeypatch.setenv("GLF_DEG_PATH", paths)
-        monkeypatch.setenv("GLF_MV_PATH", "grid" if paths == "grid" else "dense")
+    for paths in ("direct", "grid", "rank"):
+        _env_paths(monkeypatch, paths)
         _check(img, opt, 5, glf.MULTI_LOOPBACK, [0] * 5)
 
 
@@ -68,7 +71,7 @@ def test_loopback_two_ranks_1024_default_paths():
     img = glf.synth_image(1024, 1024, seed=5)
     opt = glf.default_options(num_samples=int(1024 * 1024 * 0.005), num_eigvals=64, epsilon=0.1)
     infos = _check(img, opt, 2, glf.MULTI_LOOPBACK, [0, 0])
-    assert infos[0]["nystroem_path"] == 1
+    assert infos[0]["nystroem_path"] == 3   # the rank form of the grid-factored contraction
 
 
 def test_rccl_one_rank_world():

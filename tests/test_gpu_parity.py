@@ -58,6 +58,13 @@ def _default_kernel_selection(request):
         request.getfixturevalue("ctx").reset_tuning()
 
 
+def _set_paths(ctx, paths):
+    """Kernel family of the three K_B / K_A stages: "direct" (entry by entry; stored L_A), "grid" (grid-factored, all 256 grey
+    levels) or "rank" (grid-factored with the photometric table as a rank-R expansion: the default at benchmark sizes)."""
+    ctx.set_tuning(NYS_PATH=paths, DEG_PATH="direct" if paths == "direct" else "grid",
+                   MV_PATH={"direct": "dense", "grid": "grid", "rank": "rank"}[paths])
+
+
 def _lapack_pairs(LA, m):
     w, V = np.linalg.eigh(LA)
     return np.ascontiguousarray(V[:, :m].T), w[:m]
@@ -568,14 +575,12 @@ def test_errors_are_loud(ctx):
     assert out.dtype == torch.uint8
 
 
-@pytest.mark.parametrize("paths", ["grid", "direct"])
+@pytest.mark.parametrize("paths", ["grid", "direct", "rank"])
 def test_exact_zero_skipping_is_bit_identical(ctx, paths, monkeypatch):
     """glf_options.skip_exact_zeros drops whole 64-sample chunks whose kernel entries are exactly zero
     in the arithmetic in use; the result must not change by a single bit, only the executed work."""
     import torch
-    ctx.set_tuning(NYS_PATH=paths)   # the grid-factored forms or the entry-by-entry kernels
-    ctx.set_tuning(DEG_PATH=paths)
-    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
+    _set_paths(ctx, paths)   # the grid-factored forms (all grey levels / rank form) or the entry-by-entry kernels
     img = glf.synth_image(1280, 1024, seed=11)
     d_img = ctx.to_device(img)
     ns = int(1280 * 1024 * 0.005)
@@ -613,22 +618,20 @@ def test_entire_computation_no_approx(ctx, png, shape):
     assert 0 < alpha < 1
 
 
-@pytest.mark.parametrize("paths", ["direct", "grid"])
+@pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
 @pytest.mark.parametrize("w,h,ns,m", [(16, 12, 6, 2), (24, 31, 9, 3), (200, 160, 500, 128), (256, 256, 655, 256)])
 def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     """Tiny images (p < one 64-sample chunk) and the widest supported blocks (ld = 128, 256: the MB = 4 / 8
     instantiations of the direct kernel, two / four 64-column blocks of the grid form) against the oracle.
     m = 256 is the stated upper limit of this build."""
-    ctx.set_tuning(NYS_PATH=paths)
-    ctx.set_tuning(DEG_PATH=paths)
-    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
+    _set_paths(ctx, paths)
     img = glf.synth_image(w, h, seed=21)
     eps = 0.2
     opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
     out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
     out, zf = out.cpu().numpy(), zf.cpu().numpy()
-    if paths == "grid" and info["contraction"] == glf.CONTRACT_F16_SPLIT and info["p"] >= 4:
-        assert info["nystroem_path"] == 1
+    if paths != "direct" and info["contraction"] == glf.CONTRACT_F16_SPLIT and info["p"] >= 4:
+        assert info["nystroem_path"] == (1 if paths == "grid" else 3)
     _assert_end_to_end(img, ns, m, eps, out, zf, info)
 
 
@@ -687,15 +690,13 @@ def test_nlm_kernel_end_to_end(ctx, w, h, ns, m):
     _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info, eigvals=True, prm=prm)
 
 
-@pytest.mark.parametrize("paths", ["direct", "grid"])
+@pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
 @pytest.mark.parametrize("ns,m", [(600, 0), (600, 300), (300, 257)])
 def test_more_than_256_eigenpairs_end_to_end(ctx, ns, m, paths, monkeypatch):
     """The reference's default is m = p - 1 eigenpairs (hpc/image_processing.c:96-108; num_eigvals = 0 here): beyond 256 the
     vectors are processed as panels of 256 columns (cross-panel terms of the classical Gram-Schmidt and of the residual as small
     f64 GEMMs). 256 x 192 image: p = 588 -> m = 587 = panels of 256 + 256 + 75; m = 300 and m = 257 (a one-column last panel)."""
-    ctx.set_tuning(NYS_PATH=paths)
-    ctx.set_tuning(DEG_PATH=paths)
-    ctx.set_tuning(MV_PATH="grid" if paths == "grid" else "dense")
+    _set_paths(ctx, paths)
     img = glf.synth_image(256, 192, seed=17)
     eps = 0.2
     p = glf.Sampling(256, 192, ns).size
