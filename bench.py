@@ -16,11 +16,41 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "image-processing-graph-laplacian_amd"))
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU
+    through torch.distributed.run, as the driver does) BEFORE this process touches a GPU, and leave with the ranks' exit
+    code. Fewer than N visible devices is an error, never a silent one-rank run (the reference's program IS the multi-rank
+    program: hpc/image_processing.c:30-76)."""
+    if "WORLD_SIZE" in os.environ or "--loopback" in sys.argv:
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args()[0].gpus
+    if n <= 1:
+        return
+    import torch  # (device_count does not initialise the GPU)
+    have = torch.cuda.device_count()
+    if have < n:
+        print(json.dumps({"error": "--gpus %d but only %d device(s) visible" % (n, have), "n_gpus_visible": have}))
+        sys.exit(3)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+_self_launch()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -58,6 +88,13 @@ def parse_args():
     ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
                     help="N > 1 collectives: rccl = issued by the library itself on its stream (glf_ctx_set_comm_rccl, "
                          "default); torch = torch.distributed callbacks through ctypes (the round-1 path, kept for comparison)")
+    ap.add_argument("--no-exact-leg", action="store_true",
+                    help="skip the exact_grid_form leg (the grid-factored contractions carrying all 256 grey levels: GLF_NYS_PATH / GLF_MV_PATH = grid)")
+    ap.add_argument("--no-host-leg", action="store_true",
+                    help="skip the host_to_host leg (pinned host image -> pinned host result, copies on the context's stream)")
+    ap.add_argument("--loopback", type=int, default=0,
+                    help="plumbing rehearsal, NOT a measurement: N ranks of the sharded path time-share ONE GPU through glf.Multi's "
+                         "loopback backend (host-staged collectives); prints per-rank stage times and the collectives per step")
     ap.add_argument("--no-direct-leg", action="store_true",
                     help="skip the direct_contraction leg (one step with the entry-by-entry Nystroem kernel, ~0.5 s)")
     return ap.parse_args()
@@ -209,8 +246,46 @@ def run_batch_leg(args, ctx, rank, world, barrier):
             "one_context_ms_per_tile": round(res["one_context"] * 1e3 / max(1, total), 3)}
 
 
+def run_loopback(args):
+    """N ranks on one device: the row-sharded path with every collective in place, staged through the host. What it tells:
+    the per-rank compute of an N-way split (stage times of each rank as if it had a GPU to itself are NOT measured -- the
+    ranks share the device) and the collectives per step. Flagged as a rehearsal in the line."""
+    size, N = args.size, args.size * args.size
+    img = glf.synth_image(size, size, seed=0)
+    opt = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals, epsilon=args.epsilon)
+    n = args.loopback
+    with glf.Multi(n, devices=[0] * n, backend=glf.MULTI_LOOPBACK) as mw:
+        for _ in range(args.warmup):
+            mw.image_processing(img, opt)
+        for r in range(n):
+            mw.comm_counters(r, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, _, infos = mw.image_processing(img, opt)
+        el = (time.perf_counter() - t0) / args.steps
+        cnt = mw.comm_counters(0, reset=True)
+        ci = mw.comm_info(0)
+    line = {
+        "metric": "filtered Mpixels/sec @ 4K img, 0.5% samples; PSNR vs PETSc ref",
+        "measurement": False,
+        "what": "plumbing rehearsal: %d ranks of the row-sharded path time-share ONE GPU (glf_multi loopback backend, collectives staged "
+                "through host memory, host image in / host image out); value is NOT a multi-GPU number" % n,
+        "value": round(N / el * 1e-6, 3), "unit": "Mpixel/s", "n_gpus": 1, "ranks": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el * 1e3, 3), "comm": ci,
+        "collectives_per_step_rank0": {k: v / args.steps for k, v in cnt.items()},
+        "per_rank": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in inf.items()
+                      if k in ("row0", "row1", "ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter", "ms_total", "outer_its",
+                               "inner_its_total", "matvecs", "nystroem_path", "matvec_path")} for inf in infos],
+        "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g" %
+                               (size, size, args.sample_frac * 100, infos[0]["p"], infos[0]["m"], args.epsilon)},
+    }
+    print(json.dumps(line))
+
+
 def main():
     args = parse_args()
+    if args.loopback > 0:
+        return run_loopback(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -220,9 +295,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE (launch with torch.distributed.run)" % (args.gpus, world),
-              file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print(json.dumps({"error": "--gpus %d but the launcher started WORLD_SIZE %d rank(s)" % (args.gpus, world)}))
+        sys.exit(3)
 
     size = args.size
     N = size * size
@@ -234,28 +310,29 @@ def main():
     ctx = glf.Context(local_rank)
     if world > 1 or args.force_comm:
         if args.comm == "rccl":   # the library issues its own RCCL collectives: the id travels through torch.distributed once
+            # Agree on loadability BEFORE anything collective: every rank probes librccl (glf_rccl_unique_id resolves the
+            # library; the id of the others is thrown away), the flags are MIN-reduced, and only then ncclCommInitRank runs
+            # everywhere. A failure after that point is fatal: a rank that falls out of a collective init leaves the others
+            # inside it.
             ok = 1
             try:
-                box = [glf.rccl_unique_id() if rank == 0 else None]
+                my_id = glf.rccl_unique_id()
             except Exception as e:                      # librccl not loadable on this rank
-                box, ok = [None], 0
+                my_id, ok = None, 0
                 print("rank %d: %s" % (rank, e), file=sys.stderr)
-            dist.broadcast_object_list(box, src=0)
-            if ok and box[0] is not None:
-                try:
-                    ctx.set_comm_rccl(rank, world, box[0], force=args.force_comm)
-                except Exception as e:
-                    ok = 0
-                    print("rank %d: %s" % (rank, e), file=sys.stderr)
-            else:
-                ok = 0
-            # every rank takes the same route: if the library's own communicator could not be set up anywhere, all ranks fall
-            # back to the torch.distributed callbacks (and the bench line says so)
             flag = torch.tensor([ok], dtype=torch.int32, device=ctx.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                args.comm = "torch"
+                args.comm = "torch"     # every rank takes the same route (and the bench line says so)
                 ctx.set_comm_torch(force=args.force_comm)
+            else:
+                box = [my_id if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                try:
+                    ctx.set_comm_rccl(rank, world, box[0], force=args.force_comm)
+                except Exception as e:
+                    print("rank %d: glf_ctx_set_comm_rccl failed: %s" % (rank, e), file=sys.stderr)
+                    os._exit(4)
         else:
             ctx.set_comm_torch(force=args.force_comm)
     d_img = ctx.to_device(img)
@@ -279,6 +356,7 @@ def main():
         kernel_ms = []
         mv = {"launches": 0, "ms": 0.0, "bytes": 0.0, "narrow": 0}
         rp = {"launches": 0, "ms": 0.0, "flops": 0.0}
+        cp = {"launches": 0, "ms": 0.0, "flops": 0.0}
         stage_ms = {k: 0.0 for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")}
         for _ in range(args.steps):
             _, _, info = ctx.image_processing(d_img, opt, out=d_out)
@@ -290,6 +368,9 @@ def main():
             rp["launches"] += info["nystroem_rowpass_launches"]
             rp["ms"] += info["nystroem_rowpass_ms"]
             rp["flops"] += info["nystroem_rowpass_flops"]
+            cp["launches"] += info["nystroem_colpass_launches"]
+            cp["ms"] += info["nystroem_colpass_ms"]
+            cp["flops"] += info["nystroem_colpass_flops"]
             for k in stage_ms:
                 stage_ms[k] += info[k]
         barrier()
@@ -300,11 +381,64 @@ def main():
             elapsed = float(t.item())
         info["mv"] = mv
         info["rp"] = rp
+        info["cp"] = cp
         return elapsed / args.steps, info, float(np.mean(kernel_ms)), {k[3:]: round(v / args.steps, 3) for k, v in stage_ms.items()}
 
+    if world > 1 or args.force_comm:
+        ctx.comm_counters(reset=True)
     sec_per_step, info, avg_ms, stage_ms = run_leg(opt)
     ms_per_step = sec_per_step * 1e3
     value = N / sec_per_step * 1e-6
+    # what the communicator reports, the collectives of a step, every rank's stage times
+    comm_report = None
+    if world > 1 or args.force_comm:
+        cnt = ctx.comm_counters(reset=True) if args.comm == "rccl" else {}
+        ci = ctx.comm_info() if args.comm == "rccl" else {"backend": "torch.distributed callbacks", "size": world, "rccl_ranks": world}
+        mine = {"rank": rank, "rows": [info["row0"], info["row1"]], "stage_ms": stage_ms}
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        comm_report = {"backend": ci.get("backend"), "ranks": ci.get("size"), "rccl_ranks": ci.get("rccl_ranks"),
+                       "collectives_per_step_rank0": {k: v / (args.steps + args.warmup) for k, v in cnt.items()},
+                       "per_rank": per_rank}
+
+    # host_to_host leg (SURVEY 8d's t_e2e: decoded host image bytes -> host output bytes): the image goes up and the result
+    # comes down on the context's stream, pinned buffers. Reported beside `value`, which stays the HBM-resident figure.
+    host_leg = None
+    if world == 1 and not args.no_host_leg:
+        h_img = torch.from_numpy(img).pin_memory()
+        h_out = torch.empty((size, size), dtype=torch.uint8).pin_memory()
+        d_in2 = torch.empty((size, size), dtype=torch.uint8, device=ctx.device)
+
+        def host_step():
+            with torch.cuda.stream(ctx.stream):
+                d_in2.copy_(h_img, non_blocking=True)
+            ctx.image_processing(d_in2, opt, out=d_out)
+            with torch.cuda.stream(ctx.stream):
+                h_out.copy_(d_out, non_blocking=True)
+            ctx.stream.synchronize()
+        host_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        barrier()
+        h_sec = (time.perf_counter() - t0) / args.steps
+        host_leg = {"what": "pinned host image (16.8 MB) -> device, whole path, filtered image -> pinned host buffer; copies on the context's "
+                            "stream; PNG codec excluded", "ms_per_step": round(h_sec * 1e3, 3), "value": round(N / h_sec * 1e-6, 4),
+                    "unit": "Mpixel/s", "extra_ms_over_hbm_resident": round(h_sec * 1e3 - ms_per_step, 3),
+                    "identical_to_hbm_resident_output": bool(torch.equal(h_out, d_out.cpu()))}
+
+    # exact_grid_form leg: the same step with the grid-factored contractions carrying all 256 grey levels through HBM
+    exact_leg = None
+    if not args.no_exact_leg and info["nystroem_path"] == 3:
+        ctx.set_tuning(NYS_PATH="grid", MV_PATH="grid")
+        try:
+            exact_leg = run_leg(opt)
+        finally:
+            ctx.set_tuning(NYS_PATH=None, MV_PATH=None)
     skip_leg = None
     if not args.no_skip_leg:
         opt_skip = glf.default_options(num_samples=int(N * args.sample_frac), num_eigvals=args.num_eigvals,
@@ -314,7 +448,7 @@ def main():
     # direct_contraction leg: ONE step with the entry-by-entry Nystroem kernel (k_nystroem_f16s: K_B generated in registers,
     # the "true dense contraction" of north_star, SURVEY 8d's W_nys = 2 (N - p) p m) so that it has a driver-timed number
     direct_leg = None
-    if not args.no_direct_leg and info["nystroem_path"] == 1:
+    if not args.no_direct_leg and info["nystroem_path"] in (1, 3):
         ctx.set_tuning(NYS_PATH="direct")
         try:
             ctx.image_processing(d_img, opt, out=d_out)          # warm-up (tables, pool)
@@ -347,12 +481,19 @@ def main():
         ld = 32
         while ld < m:
             ld *= 2
-        grid_path = info["nystroem_path"] == 1
+        grid_path = info["nystroem_path"] in (1, 3)
+        rank_path = info["nystroem_path"] == 3
+        R = info.get("rank_terms", 0)
         issued = info["nystroem_mfma_flops"] / (avg_ms * 1e-3) / 1e12
         if info["contraction"] == glf.CONTRACT_F16_SPLIT:
             # every f32-equivalent multiply-add is three f16 MFMA products (hi*hi + hi*lo + lo*hi)
             nys_peak = PEAK_F16_MFMA_TFLOPS
-            if grid_path:
+            if rank_path:
+                nys_kernel = ("k_grid_rowpass_rt<RANK> + k_rank_colpass<%d> (grid-factored Nystroem contraction, rank form: the photometric "
+                              "table P(|v - w|) as its rank-%d eigen-expansion F F^T (max error <= 2^-30); S[r][b][k] = sum_a Er f_k(v_ab) Psi "
+                              "on v_mfma_f32_32x32x16_f16 with both operands split into f16 hi+lo pairs, then per (image row, segment of <= 32 "
+                              "values) T' = F S formed in LDS and Phi = sum_b Ec T' the same way -- T never reaches HBM)" % (R // 16, R))
+            elif grid_path:
                 nys_kernel = ("k_grid_rowpass_rt<%d> + k_grid_colpass<%d> (grid-factored Nystroem contraction: "
                               "T[r][v][b] = sum_a Er (P Psi) on v_mfma_f32_32x32x16_f16 with both operands split into f16 hi+lo "
                               "pairs, then Phi = sum_b Ec T the same way)" % (ld // 32, ld // 32))
@@ -364,7 +505,8 @@ def main():
             nys_peak = PEAK_F32_MFMA_TFLOPS
             nys_kernel = "k_nystroem<%d,%d> (direct Nystroem contraction, v_mfma_f32_32x32x2_f32)" % (ld // 32, 2 if ld <= 128 else 1)
         nystroem = {
-            "kernel": nys_kernel, "path": "grid-factored" if grid_path else "direct",
+            "kernel": nys_kernel, "path": "grid-factored, rank form (NYS_PATH=rank)" if rank_path else "grid-factored" if grid_path else "direct",
+            "rank_terms": R,
             "avg_ms_per_step": round(avg_ms, 3), "launches_per_step": info["nystroem_launches"],
             "algorithmic_flops": flops, "algorithmic_tflops": round(achieved, 1),
             "mfma_issued_tflops": round(issued, 1), "mfma_peak_tflops": nys_peak,
@@ -382,7 +524,8 @@ def main():
             prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key, {})
         except (OSError, ValueError):
             pass
-        sweeps = {"path": "grid-factored (L_A never stored)" if info["matvec_path"] == 1 else "stored L_A streamed (k_block_matvec_f16s)",
+        sweeps = {"path": ("grid-factored, rank form (L_A never stored; S = 0.7 GB per sweep instead of T = 5.6 GB)" if info["matvec_path"] == 3 else
+                           "grid-factored (L_A never stored)" if info["matvec_path"] == 1 else "stored L_A streamed (k_block_matvec_f16s)"),
                   "launches_per_step": mvs["launches"] / args.steps, "avg_ms": round(mv_avg_ms, 4),
                   "ms_per_step": round(mvs["ms"] / args.steps, 3),
                   "narrow_per_step": mvs["narrow"] / args.steps,
@@ -390,7 +533,37 @@ def main():
         # (image row, value) pairs that occur in the image: the T rows the row pass has to deliver (the others are computed
         # by the 32-row MFMA tiles but never stored or read)
         present = float(np.mean([np.unique(img[r]).size for r in range(info["row0"], info["row1"])])) / 256.0
-        if info["matvec_path"] == 1 and rps["launches"] > 0:
+        cps = info["cp"]
+        if rank_path and cps["launches"] > 0:
+            # dominant kernel of the rank form: the fused T' + column pass of the Nystroem stage (the L_A sweeps run the same kernel
+            # over the nr grid rows)
+            cp_avg_ms = cps["ms"] / cps["launches"]
+            cp_flops = cps["flops"] / cps["launches"]
+            cp_tflops = cp_flops / (cp_avg_ms * 1e-3) / 1e12
+            cp_peak = PEAK_F16_MFMA_TFLOPS / 3.0
+            rp_avg_ms = rps["ms"] / max(1, rps["launches"])
+            roofline = {
+                "kernel": "k_rank_colpass<%d,false> (per image row and segment of <= 32 grey values: T'[v][b][n] = sum_k f_k(v) S[r][b][k][n] "
+                          "formed block by block of 16 sample columns in LDS, then Phi[px][n] = sum_b Ec(c_px - C_b) T'[v_px][b][n], both on "
+                          "v_mfma_f32_32x32x16_f16 with operands split into f16 hi+lo, f32 accumulate; persistent workgroups)" % (R // 16),
+                "bound": "mfma", "achieved": round(cp_tflops, 1), "peak": round(cp_peak, 1), "unit": "TFLOP/s",
+                "frac": round(cp_tflops / cp_peak, 4), "traffic": prof.get("rank_colpass_bytes_per_launch"),
+                "traffic_source": prof.get("rank_colpass_source", "none: no committed --pmc pass for this configuration"),
+                "algorithmic_bytes": 4.0 * (N * (ld if ld < 64 else 64) * (ld // min(ld, 64)) + info["p"] // max(1, int(np.sqrt(info["p"]))) * 0) ,
+                "avg_launch_ms": round(cp_avg_ms, 4), "launches_per_step": cps["launches"] / args.steps,
+                "flops_per_launch": cp_flops, "ms_per_step": round(cps["ms"] / args.steps, 3),
+                "row_pass": {"kernel": "k_grid_rowpass_rt<1,.,4,2,8,.,RANK> (S[r][b][k] = sum_a Er(r - R_a) f_k(v_ab) Psi[(a,b)])",
+                             "avg_launch_ms": round(rp_avg_ms, 4), "launches_per_step": rps["launches"] / args.steps,
+                             "tflops": round(rps["flops"] / max(1e-9, rps["ms"] * 1e-3) / 1e12, 1),
+                             "frac_of_peak": round(rps["flops"] / max(1e-9, rps["ms"] * 1e-3) / 1e12 / cp_peak, 4)},
+                "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add (nominal)",
+                "note": "achieved = algorithmic flops of the launch -- 2 ld ncs (sum over rows of (values present) R + pixels): T' for the "
+                        "(row, value) pairs that occur, then the Ec contraction per pixel; one product per multiply-add -- / mean HIP-event "
+                        "duration of the launch. The MFMAs executed are ~2.5x that (32-value and 32-pixel tiles are part-filled: ~23 of 32 "
+                        "slots, ~19 of 32 pixels per chunk at cfg4). traffic = FETCH_SIZE x 2 + WRITE_SIZE of the launch from the committed "
+                        "rocprofv3 --pmc passes named in traffic_source: the S stream (read once from HBM, re-read ~9x from L2) + the Phi write"}
+            roofline.pop("algorithmic_bytes")
+        elif info["matvec_path"] == 1 and rps["launches"] > 0:
             # dominant kernel: the row pass of the Nystroem contraction (k_grid_rowpass_rt; by name the largest share of the step)
             rp_avg_ms = rps["ms"] / rps["launches"]
             rp_flops = rps["flops"] / rps["launches"]
@@ -437,6 +610,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g, "
                                    "no exact-zero skipping (every kernel entry enters the sums: %s)" % (size, size, args.sample_frac * 100, p, m, args.epsilon,
+                                   "grid-factored forms, rank-%d photometric expansion" % R if rank_path else
                                    "grid-factored forms" if info["nystroem_path"] == 1 else "entry-by-entry kernels"),
                        "N": N, "p": p, "m": m, "epsilon": args.epsilon, "outer_its": info["outer_its"],
                        "inner_its_total": info["inner_its_total"], "residual": round(info["residual"], 5),
@@ -453,6 +627,18 @@ def main():
             "eigen_sweeps": sweeps,
             "nystroem": nystroem,
         }
+        if comm_report is not None:
+            line["comm"] = comm_report
+            line["rccl_ranks"] = comm_report.get("rccl_ranks")
+        if host_leg is not None:
+            line["host_to_host"] = host_leg
+        if exact_leg is not None:
+            e_sec, e_info, e_avg_ms, e_stage = exact_leg
+            line["exact_grid_form"] = {
+                "what": "same workload with GLF_NYS_PATH = GLF_MV_PATH = grid: the grid-factored contractions carrying all 256 grey levels "
+                        "(T = 78 GB per image through HBM); the rank form replaces the photometric table by its rank-%d expansion" % R,
+                "value": round(N / e_sec * 1e-6, 4), "unit": "Mpixel/s", "ms_per_step": round(e_sec * 1e3, 3), "stage_ms_rank0": e_stage,
+                "outer_its": e_info["outer_its"], "inner_its_total": e_info["inner_its_total"]}
         if skip_leg is not None:
             s_sec, s_info, s_avg_ms, s_stage = skip_leg
             dense_evals = float(p) * npix_local

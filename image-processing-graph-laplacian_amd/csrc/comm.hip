@@ -34,18 +34,30 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional: what the communicator itself reports, and the way out when a rank fails outside a collective
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     bool ok = false;
+    char load_error[256] = {0}; // dlerror() text of the last failed dlopen (captured once: dlerror() clears itself)
 };
 
+static RcclApi g_rccl_api_storage;
 static RcclApi *rccl_api()
 {
-    static RcclApi api;
+    RcclApi &api = g_rccl_api_storage;
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [&api] {
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) // an RCCL the process already carries (torch's) first
             if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-        for (int i = 0; !api.handle && i < 3; ++i) api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        for (int i = 0; !api.handle && i < 3; ++i) {
+            api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+            if (!api.handle) {
+                const char *e = dlerror();
+                std::snprintf(api.load_error, sizeof(api.load_error), "%s", e ? e : "not found");
+            }
+        }
         if (!api.handle) return;
 #define GLF_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, name))
         GLF_SYM(GetUniqueId, "ncclGetUniqueId");
@@ -55,6 +67,9 @@ static RcclApi *rccl_api()
         GLF_SYM(AllReduce, "ncclAllReduce");
         GLF_SYM(AllGather, "ncclAllGather");
         GLF_SYM(GetErrorString, "ncclGetErrorString");
+        GLF_SYM(CommCount, "ncclCommCount");
+        GLF_SYM(CommUserRank, "ncclCommUserRank");
+        GLF_SYM(CommAbort, "ncclCommAbort");
 #undef GLF_SYM
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.AllReduce && api.AllGather;
     });
@@ -67,12 +82,17 @@ struct NativeComm {
     ncclComm_t nccl = nullptr;     // RCCL backend
     struct Loopback *loop = nullptr; // loopback backend
     int rank = 0, size = 1;
+    // collectives issued since the counters were last read (glf_ctx_comm_counters): calls and payload bytes of this rank
+    unsigned long long n_allreduce = 0, n_allgather = 0, bytes_allreduce = 0, bytes_allgather = 0;
 };
 
 static int rccl_allreduce(NativeComm *nc, void *buf, size_t count, ncclDataType_t dt)
 {
     RcclApi *api = rccl_api();
     if (!api) return 1;
+    if (!nc->nccl) return 1; // aborted
+    ++nc->n_allreduce;
+    nc->bytes_allreduce += count * (dt == ncclFloat64 ? 8 : 4);
     const ncclResult_t r = api->AllReduce(buf, buf, count, dt, ncclSum, nc->nccl, nc->ctx->stream);
     if (r != ncclSuccess) {
         set_error(nc->ctx, GLF_ERR_COMM, "ncclAllReduce -> %s", api->GetErrorString ? api->GetErrorString(r) : "error");
@@ -87,6 +107,9 @@ static int rccl_allgather_f32(void *user, float *d, size_t count_per_rank)
     NativeComm *nc = static_cast<NativeComm *>(user);
     RcclApi *api = rccl_api();
     if (!api) return 1;
+    if (!nc->nccl) return 1; // aborted
+    ++nc->n_allgather;
+    nc->bytes_allgather += count_per_rank * sizeof(float) * (size_t)nc->size; // (what lands in this rank's buffer)
     // in place: rank r's block already sits at offset r * count_per_rank of the receive buffer
     const ncclResult_t r = api->AllGather(d + (size_t)nc->rank * count_per_rank, d, count_per_rank, ncclFloat32, nc->nccl, nc->ctx->stream);
     if (r != ncclSuccess) {
@@ -130,6 +153,8 @@ static int loop_allreduce(NativeComm *nc, T *d, size_t n)
 {
     Loopback *L = nc->loop;
     if (L->broken) return 1;
+    ++nc->n_allreduce;
+    nc->bytes_allreduce += n * sizeof(T);
     std::vector<char> &mine = L->slot[nc->rank];
     mine.resize(n * sizeof(T));
     if (hipMemcpyAsync(mine.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, nc->ctx->stream) != hipSuccess) return 1;
@@ -155,6 +180,8 @@ static int loop_allgather_f32(void *user, float *d, size_t count_per_rank)
     Loopback *L = nc->loop;
     if (L->broken) return 1;
     const size_t bytes = count_per_rank * sizeof(float);
+    ++nc->n_allgather;
+    nc->bytes_allgather += bytes * (size_t)L->size;
     std::vector<char> &mine = L->slot[nc->rank];
     mine.resize(bytes);
     if (hipMemcpyAsync(mine.data(), d + (size_t)nc->rank * count_per_rank, bytes, hipMemcpyDeviceToHost, nc->ctx->stream) != hipSuccess) return 1;
@@ -219,6 +246,7 @@ struct glf_multi {
         bool has_zf = false;
     };
     std::vector<Buffers> buf;
+    bool broken = false; // RCCL backend: a rank failed and the communicators were aborted -- the world cannot be used again
     char last_error[512] = {0};
 };
 
@@ -241,7 +269,7 @@ int glf_ctx_set_comm_rccl(glf_ctx *ctx, int rank, int size, const void *unique_i
     if (!ctx || size < 1 || rank < 0 || rank >= size || !unique_id || bytes < sizeof(ncclUniqueId)) return GLF_ERR_INVALID;
     GLF_ENTER(ctx);
     RcclApi *api = rccl_api();
-    if (!api) return set_error(ctx, GLF_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "not found");
+    if (!api) return set_error(ctx, GLF_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", g_rccl_api_storage.load_error);
     native_comm_release(ctx);
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof(id));
@@ -256,6 +284,40 @@ int glf_ctx_set_comm_rccl(glf_ctx *ctx, int rank, int size, const void *unique_i
     ctx->force_comm = force != 0;
     ctx->native = n.release();
     install(ctx, &ctx->native->nc, true);
+    return GLF_OK;
+}
+
+/* What the communicator of a context reports: info = {rank, size, backend (0 none / caller's callbacks, 1 RCCL, 2 loopback),
+ * ranks the RCCL communicator itself counts (ncclCommCount; 0 when not RCCL)}. */
+int glf_ctx_comm_info(glf_ctx *ctx, int info[4])
+{
+    if (!ctx || !info) return GLF_ERR_INVALID;
+    info[0] = ctx->comm.rank;
+    info[1] = ctx->comm.size;
+    info[2] = 0;
+    info[3] = 0;
+    if (glf_native_comm *n = ctx->native) {
+        info[2] = n->nc.loop ? 2 : 1;
+        if (!n->nc.loop && n->nc.nccl)
+            if (RcclApi *api = rccl_api())
+                if (api->CommCount) (void)api->CommCount(n->nc.nccl, &info[3]);
+    }
+    return GLF_OK;
+}
+
+/* Collectives this rank issued through the library's own communicator since the last reset:
+ * out = {all-reduce calls, all-reduce bytes, all-gather calls, all-gather bytes (received)}. */
+int glf_ctx_comm_counters(glf_ctx *ctx, unsigned long long out[4], int reset)
+{
+    if (!ctx || !out) return GLF_ERR_INVALID;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (glf_native_comm *n = ctx->native) {
+        out[0] = n->nc.n_allreduce;
+        out[1] = n->nc.bytes_allreduce;
+        out[2] = n->nc.n_allgather;
+        out[3] = n->nc.bytes_allgather;
+        if (reset) n->nc.n_allreduce = n->nc.bytes_allreduce = n->nc.n_allgather = n->nc.bytes_allgather = 0;
+    }
     return GLF_OK;
 }
 
@@ -336,8 +398,13 @@ int glf_multi_image_processing(glf_multi *w, const glf_options *opt, const uint8
                                float *h_zf, double *eigvals_out, glf_stats *stats)
 {
     if (!w || !h_img || !h_out || width <= 0 || height <= 0) return GLF_ERR_INVALID;
+    if (w->broken) {
+        std::snprintf(w->last_error, sizeof(w->last_error), "the communicators of this world were aborted after a rank failed; create a new one");
+        return GLF_ERR_COMM;
+    }
     const size_t N = (size_t)width * height;
     std::vector<int> rcs(w->n, GLF_OK);
+    std::mutex abort_mu;
     auto rank_main = [&](int r) {
         glf_ctx *ctx = w->ctxs[r];
         glf_multi::Buffers &b = w->buf[r];
@@ -374,6 +441,25 @@ int glf_multi_image_processing(glf_multi *w, const glf_options *opt, const uint8
             if (stats) stats[r] = st;
         }
         if (rc != GLF_OK && w->loop) w->loop->abort_all(); // the other ranks must not wait for this one
+        if (rc != GLF_OK && !w->loop) {
+            // RCCL: the peers may sit in a collective this rank will never join (it failed outside one: out of memory, a launch
+            // error, no convergence on this rank only) and their streams would never drain. Abort every communicator of the
+            // world: the pending collectives return an error, the rank threads come back, the world is marked unusable.
+            std::lock_guard<std::mutex> lk(abort_mu);
+            if (!w->broken) {
+                w->broken = true;
+                if (RcclApi *api = rccl_api())
+                    if (api->CommAbort)
+                        for (int q = 0; q < w->n; ++q) {
+                            glf_native_comm *nat = w->ctxs[q]->native;
+                            if (nat && nat->nc.nccl) {
+                                (void)api->CommAbort(nat->nc.nccl);
+                                nat->nc.nccl = nullptr;
+                                nat->owns_nccl = false;
+                            }
+                        }
+            }
+        }
         rcs[r] = rc;
     };
     if (w->loop) {

@@ -143,6 +143,9 @@ int glf_ctx_destroy(glf_ctx *ctx)
     for (auto &row : ctx->mv_ev)
         for (auto &e : row)
             if (e) (void)hipEventDestroy(e);
+    for (auto &row : ctx->cp_ev)
+        for (auto &e : row)
+            if (e) (void)hipEventDestroy(e);
     glf::native_comm_release(ctx);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->x0_block) (void)hipFree(ctx->x0_block);

@@ -60,6 +60,8 @@ struct glf_ctx {
     // timing of the L_A sweeps (the HBM-bound kernel): a ring of event pairs, summed by mv_collect()
     static constexpr int MV_RING = 64;
     hipEvent_t mv_ev[2][MV_RING] = {};
+    static constexpr int CP_RING = 16; // event pairs around the rank-form column-pass launches of one call (created on first use)
+    hipEvent_t cp_ev[2][CP_RING] = {};
     int mv_pending = 0;
     unsigned call_no = 0; // public entry points so far (ages the cached work buffers: pool_get)
     int mv_count = 0;
@@ -310,6 +312,11 @@ struct RowpassStats {
     int launches = 0;
     float ms = 0.f;
     double flops = 0.0;
+    // rank form: the fused T' + column-pass kernel, and the terms of the photometric expansion
+    int col_launches = 0;
+    float col_ms = 0.f;
+    double col_flops = 0.0;
+    int rank_R = 0;
 };
 struct GridOp; // L_A = alpha (D - K_A) applied in grid-factored form, never stored (nystroem_grid.inc)
 int grid_op_create(glf_ctx *ctx, const float4 *d_samples, const unsigned *h_idx, unsigned p, int width, int height,

@@ -730,6 +730,10 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     S.nystroem_rowpass_launches = rps.launches;
     S.nystroem_rowpass_ms = rps.ms;
     S.nystroem_rowpass_flops = rps.flops;
+    S.nystroem_colpass_launches = rps.col_launches;
+    S.nystroem_colpass_ms = rps.col_ms;
+    S.nystroem_colpass_flops = rps.col_flops;
+    S.rank_terms = rps.rank_R;
     S.nystroem_launches = 1;
     S.nystroem_kernel_ms = kms;
     S.contraction = ctx->contraction;

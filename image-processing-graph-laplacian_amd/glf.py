@@ -41,7 +41,7 @@ RCCL_ID_BYTES = 128
 # every symbol include/glf.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "glf_strerror", "glf_ctx_create", "glf_ctx_destroy", "glf_ctx_synchronize", "glf_ctx_last_error",
-    "glf_ctx_device_info", "glf_ctx_set_tuning", "glf_ctx_set_comm", "glf_rccl_unique_id", "glf_ctx_set_comm_rccl", "glf_multi_create", "glf_multi_destroy",
+    "glf_ctx_device_info", "glf_ctx_set_tuning", "glf_ctx_set_comm", "glf_rccl_unique_id", "glf_ctx_set_comm_rccl", "glf_ctx_comm_info", "glf_ctx_comm_counters", "glf_multi_create", "glf_multi_destroy",
     "glf_multi_size", "glf_multi_ctx", "glf_multi_last_error", "glf_multi_image_processing", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
     "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_mat_get_column", "glf_Sampling",
     "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
@@ -88,6 +88,8 @@ class Stats(C.Structure):
         ("nystroem_evaluated", C.c_double), ("degree_evaluated", C.c_double),
         ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("matvec_path", C.c_int32),
         ("nystroem_rowpass_launches", C.c_int32), ("nystroem_rowpass_ms", C.c_float), ("nystroem_rowpass_flops", C.c_double),
+        ("nystroem_colpass_launches", C.c_int32), ("nystroem_colpass_ms", C.c_float), ("nystroem_colpass_flops", C.c_double),
+        ("rank_terms", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -297,9 +299,41 @@ class Multi:
             raise GlfError(rc, "glf_multi_image_processing: " + _lib.glf_multi_last_error(self._w).decode())
         infos = [dict(p=s.p, m=s.m, alpha=s.alpha, outer_its=s.eig.outer_its, inner_its_total=s.eig.inner_its_total,
                       residual=s.eig.residual, row0=s.row0, row1=s.row1, ms_total=s.ms_total, ms_eigen=s.ms_eigen,
-                      ms_nystroem=s.ms_nystroem, ms_affinity=s.ms_affinity, nystroem_path=s.nystroem_path,
+                      ms_nystroem=s.ms_nystroem, ms_affinity=s.ms_affinity, ms_laplacian=s.ms_laplacian, ms_filter=s.ms_filter,
+                      matvecs=s.eig.matvecs, nystroem_path=s.nystroem_path,
                       matvec_path=s.matvec_path, eigvals=lam[:s.m].copy()) for s in stats]
         return out, zf, infos
+
+    def comm_counters(self, rank=0, reset=True):
+        """Collectives rank `rank` issued since the last reset: dict(allreduce_calls, allreduce_bytes, allgather_calls, allgather_bytes)."""
+        return _comm_counters(C.c_void_p(_lib.glf_multi_ctx(self._w, C.c_int(rank))), reset)
+
+    def comm_info(self, rank=0):
+        return _comm_info(C.c_void_p(_lib.glf_multi_ctx(self._w, C.c_int(rank))))
+
+    def set_tuning(self, **kw):
+        for r in range(self.n):
+            for k, v in kw.items():
+                rc = _lib.glf_ctx_set_tuning(C.c_void_p(_lib.glf_multi_ctx(self._w, C.c_int(r))), k.encode(), None if v is None else str(v).encode())
+                if rc != OK:
+                    raise GlfError(rc, "set_tuning(%s=%r)" % (k, v))
+
+
+def _comm_counters(ctx_ptr, reset=True):
+    out = (C.c_ulonglong * 4)()
+    rc = _lib.glf_ctx_comm_counters(ctx_ptr, out, C.c_int(1 if reset else 0))
+    if rc != OK:
+        raise GlfError(rc, "glf_ctx_comm_counters")
+    return dict(allreduce_calls=int(out[0]), allreduce_bytes=int(out[1]), allgather_calls=int(out[2]), allgather_bytes=int(out[3]))
+
+
+def _comm_info(ctx_ptr):
+    info = (C.c_int * 4)()
+    rc = _lib.glf_ctx_comm_info(ctx_ptr, info)
+    if rc != OK:
+        raise GlfError(rc, "glf_ctx_comm_info")
+    return dict(rank=int(info[0]), size=int(info[1]), backend={0: "none", 1: "rccl", 2: "loopback"}.get(int(info[2]), "?"),
+                rccl_ranks=int(info[3]))
 
 
 # ---- device context --------------------------------------------------------------------
@@ -380,6 +414,14 @@ class Context:
         self._native_rank = (rank, size)
         self._check(_lib.glf_ctx_set_comm_rccl(self._ctx, C.c_int(rank), C.c_int(size), buf, C.c_size_t(RCCL_ID_BYTES),
                                                C.c_int(1 if force else 0)), "set_comm_rccl")
+
+    def comm_info(self):
+        """What the context's communicator reports: dict(rank, size, backend, rccl_ranks = ncclCommCount)."""
+        return _comm_info(self._ctx)
+
+    def comm_counters(self, reset=True):
+        """Collectives this rank issued through the library's own communicator since the last reset."""
+        return _comm_counters(self._ctx, reset)
 
     def set_comm_torch(self, group=None, shard_eigensolve=True, force=False):
         """Plug torch.distributed all-reduces into glf_comm: RCCL on the device buffers in place
@@ -624,7 +666,8 @@ class Context:
                     nystroem_evaluated=st.nystroem_evaluated, degree_evaluated=st.degree_evaluated,
                     nystroem_mfma_flops=st.nystroem_mfma_flops, nystroem_path=st.nystroem_path, matvec_path=st.matvec_path,
                     nystroem_rowpass_launches=st.nystroem_rowpass_launches, nystroem_rowpass_ms=st.nystroem_rowpass_ms,
-                    nystroem_rowpass_flops=st.nystroem_rowpass_flops,
+                    nystroem_rowpass_flops=st.nystroem_rowpass_flops, nystroem_colpass_launches=st.nystroem_colpass_launches,
+                    nystroem_colpass_ms=st.nystroem_colpass_ms, nystroem_colpass_flops=st.nystroem_colpass_flops, rank_terms=st.rank_terms,
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     narrow_sweeps=st.eig.narrow_sweeps,
                     eigvals=lam[:st.m].copy())

@@ -117,6 +117,13 @@ int glf_ctx_set_comm_rccl(glf_ctx *ctx, int rank, int size, const void *unique_i
  * xGMI). GLF_MULTI_LOOPBACK: the same collectives staged through host memory between the rank threads in fixed rank
  * order; ranks may share a device (devices[i] may repeat), which RCCL refuses -- this is how the N > 1 sharding of the C
  * path is tested on a one-GPU box. devices == NULL: 0 .. n-1. */
+/* info = {rank, size, backend (0 none / caller's callbacks, 1 RCCL, 2 loopback), ranks the RCCL communicator itself reports
+ * (ncclCommCount; 0 when not RCCL)} */
+int glf_ctx_comm_info(glf_ctx *ctx, int info[4]);
+/* collectives issued through the library's own communicator since the last reset:
+ * out = {all-reduce calls, all-reduce bytes, all-gather calls, all-gather bytes received} */
+int glf_ctx_comm_counters(glf_ctx *ctx, unsigned long long out[4], int reset);
+
 typedef struct glf_multi glf_multi;
 enum { GLF_MULTI_RCCL = 0, GLF_MULTI_LOOPBACK = 1 };
 int glf_multi_create(glf_multi **w, int n, const int *devices, int backend);
@@ -325,6 +332,15 @@ typedef struct glf_stats {
     int32_t nystroem_rowpass_launches;
     float nystroem_rowpass_ms;
     double nystroem_rowpass_flops;
+    /* rank form (nystroem_path 3): the fused T' + column-pass kernel (k_rank_colpass) -- launches, summed device ms (HIP
+     * events around each launch), its algorithmic flops 2 ld ncs (sum over rows of (values present) R + pixels) (one product
+     * per multiply-add: T' for the (row, value) pairs that occur, then the Ec contraction per pixel), and R, the terms of the
+     * expansion of the photometric table (0: exact form) */
+    int32_t nystroem_colpass_launches;
+    float nystroem_colpass_ms;
+    double nystroem_colpass_flops;
+    int32_t rank_terms;
+    int32_t reserved_;
 } glf_stats;
 
 /* ApproximationComputation, hpc/image_processing.c:183-277 (commented tail
