@@ -202,6 +202,9 @@ def parity_headline(ctx, img, cap_run, args):
                             phi_gpu=lambda r: phi_v[r, :, :m].cpu().numpy(), zf_gpu=lambda r: zf[r].cpu().numpy(),
                             out_gpu=lambda r: out[r].cpu().numpy(), gain=3.0, corr_gpu=lambda r: corr_v[r].cpu().numpy())
     res["degree_max_rel_err_12_samples"] = d_rel
+    res["how_much_the_filter_did"] = ("psnr_ref_vs_input_db = PSNR of the reference's 8-bit output against the INPUT on these rows (inf: equal); "
+                                      "rms_correction_grey_levels = RMS of z - y: with the reference's gain 3.0 the filter moves a pixel by ~1e-3 "
+                                      "grey levels at this size, so psnr_db / u8_* say little -- tests/test_gpu_large.py has a gain = 2000 case")
     res["cpu_seconds"] = round(time.time() - t0, 1)
     res["what"] = ("rows %s of the %dx%d run vs the fp64 oracle fed the run's Phi_A, eigenvalues, alpha and c = Phi^T y; "
                    "psnr_db / u8_* on the 8-bit output rows, rel_l2_correction on z - y" % (rows, size, size))

@@ -63,7 +63,7 @@ def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, g
     num_c = den_c = num_z = den_z = num_k = 0.0
     u8_equal = u8_within1 = npx = 0
     u8_maxdiff = 0
-    mse = 0.0
+    mse = mse_in = 0.0
     for r in rows:
         ref = orc.nystroem_rows(img, idx, alpha, phi_A64, lam, r, r + 1, prm=prm).T      # [W, m], extension formula
         for c_px in range(w):                                                          # sample pixels keep phi_A (hpc/nystroem.c:25-34)
@@ -91,9 +91,13 @@ def check_rows(img, idx, alpha, phi_A, lam, c, rows, phi_gpu, zf_gpu, out_gpu, g
         u8_within1 += int(np.sum(d <= 1))
         u8_maxdiff = max(u8_maxdiff, int(d.max()))
         mse += float(np.sum(d.astype(np.float64) ** 2))
+        mse_in += float(np.sum((out_ref.astype(np.float64) - img[r].astype(np.float64)) ** 2))   # how much the filter did
         npx += w
     mse /= max(1, npx)
+    mse_in /= max(1, npx)
     return {
+        # PSNR of the reference output against the INPUT rows: how visible the filter is (inf: the 8-bit output equals the input)
+        "psnr_ref_vs_input_db": float("inf") if mse_in == 0 else float(10.0 * np.log10(255.0 ** 2 / mse_in)),
         "rows": [int(r) for r in rows], "pixels": npx,
         "phi_max_abs_err_over_max": phi_err_max / phi_ref_max if phi_ref_max > 0 else 0.0,
         "phi_max_rel_err_big_entries": rel_big,          # entries > 1e-3 max|Phi row|

@@ -75,11 +75,15 @@ def _residual_fp64(torch, LA, p, X):
     return float(torch.linalg.norm(R)), torch.linalg.eigvalsh(0.5 * (G + G.T)).cpu().numpy()
 
 
-@pytest.mark.parametrize("size,form", [(2048, "rank"), (2048, "grid"), (4096, "rank"), (4096, "grid")])
-def test_headline_config_sampled_parity(ctx, size, form):
+@pytest.mark.parametrize("size,form,gain", [(1024, "rank", 3.0), (2048, "rank", 3.0), (2048, "grid", 3.0), (2048, "rank", 2000.0),
+                                            (4096, "rank", 3.0), (4096, "grid", 3.0)])
+def test_headline_config_sampled_parity(ctx, size, form, gain):
     """form: "rank" = the default kernels (grid-factored contractions with the photometric table as a rank-R expansion, T'
     formed in LDS: what bench.py's headline times), "grid" = the same contractions carrying all 256 grey levels through
-    HBM (GLF_NYS_PATH / GLF_MV_PATH = grid: bench.py's second leg)."""
+    HBM (GLF_NYS_PATH / GLF_MV_PATH = grid: bench.py's second leg). 1024: BASELINE cfg5's tile (m = 64, whole path). gain:
+    hpc/display.c:73 has 3.0, with which the filter moves a pixel by ~1e-3 grey levels at these sizes -- the 8-bit output
+    is y or y - 1 and its comparison nearly vacuous; the gain = 2000 case moves pixels by several grey levels, so that the
+    u8 / PSNR comparison with the oracle can fail."""
     torch = ctx.torch
     ctx.reset_tuning()
     if form == "grid":
@@ -90,9 +94,12 @@ def test_headline_config_sampled_parity(ctx, size, form):
     ns = int(N * 0.005)
     idx = glf.Sampling(size, size, ns)
     p = idx.size
-    assert p == {2048: 21316, 4096: 85264}[size]
+    assert p == {1024: 5329, 2048: 21316, 4096: 85264}[size]
     d_img = ctx.to_device(img)
     opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    opt.gain = gain
+    if size == 1024:
+        ctx.set_tuning(MV_PATH="rank")        # (auto keeps a stored L_A below 16384 samples; the tile goes through the rank form here)
     out, zf, info = ctx.image_processing(d_img, opt, want_float=True, capture=True)
     ctx.reset_tuning()
     cap = info["capture"]
@@ -128,7 +135,7 @@ def test_headline_config_sampled_parity(ctx, size, form):
     assert np.all(np.isfinite(lam)) and np.all(lam > 0)
     report["eigval_vs_ritz_max_rel"] = float(np.max(np.abs(np.sort(lam) / ritz - 1.0)))
     assert report["eigval_vs_ritz_max_rel"] <= 0.5                    # sanity only: the reference's 1 / |u_j| estimates (:204) are loose at eps = 0.1
-    if size == 2048:
+    if size <= 2048 and gain == 3.0:
         KA, _ = orc.affinity(img, idx, want_KB=False)
         LA_ref, alpha_ref = orc.laplacian(KA, D)
         del KA
@@ -156,18 +163,21 @@ def test_headline_config_sampled_parity(ctx, size, form):
     phi_v = phi.view(size, size, 64)
     res = parity.check_rows(img, idx, info["alpha"], phi_A.cpu().numpy(), lam, c64, rows,
                             phi_gpu=lambda r: phi_v[r, :, :m].cpu().numpy(), zf_gpu=lambda r: zf[r].cpu().numpy(),
-                            out_gpu=lambda r: out[r].cpu().numpy(), gain=3.0, corr_gpu=lambda r: cap["corr"].view(size, size)[r].cpu().numpy())
+                            out_gpu=lambda r: out[r].cpu().numpy(), gain=gain, corr_gpu=lambda r: cap["corr"].view(size, size)[r].cpu().numpy())
     report["rows_check"] = res
+    if gain > 100.0:     # the filter must be visible in this case: the reference output differs from the input by >= 1 grey level RMS
+        assert res["rms_correction_grey_levels"] >= 1.0 and res["psnr_ref_vs_input_db"] < 48.0
     report["eigvals_min_max"] = [float(lam.min()), float(lam.max())]
-    _record("large_parity_%d%s.json" % (size, "" if form == "rank" else "_grid"), report)
+    _record("large_parity_%d%s%s.json" % (size, "" if form == "rank" else "_grid", "" if gain == 3.0 else "_gain%g" % gain), report)
     print(json.dumps(report, default=float))
     assert res["phi_max_abs_err_over_max"] <= PHI_TOL
     assert res["rel_l2_correction"] <= CORR_TOL                       # the correction term z - y itself
-    assert res["rms_err_z_grey_levels"] <= Z_RMS_TOL                  # and the float z (ulp-bound)
+    z_tol = Z_RMS_TOL + CORR_TOL * res["rms_correction_grey_levels"]  # (ulp(z)-bound; a large gain scales the correction's own error)
+    assert res["rms_err_z_grey_levels"] <= z_tol                      # and the float z
     assert res["u8_within1_frac"] >= 0.999 and res["u8_max_diff"] <= 1
     assert res["psnr_db"] >= 50.0
     # the whole image: every pixel's correction follows from its Phi row -- z recomputed in fp64 from the captured Phi
-    wv = torch.from_numpy(3.0 * lam * c64).to(ctx.device)
+    wv = torch.from_numpy(gain * lam * c64).to(ctx.device)
     corr = torch.empty(N, dtype=torch.float64, device=ctx.device)
     for i0 in range(0, N, 1 << 20):                                    # (one 16.7M-row gemv is more than hipBLAS launches)
         corr[i0:i0 + (1 << 20)] = (phi[i0:i0 + (1 << 20), :m].double() * wv).sum(1)
@@ -175,11 +185,11 @@ def test_headline_config_sampled_parity(ctx, size, form):
     rel_all = float(torch.linalg.norm(cap["corr"].double() - corr) / torch.linalg.norm(corr))
     report["rel_l2_correction_all_pixels_vs_fp64_from_gpu_phi"] = rel_all
     assert rel_all <= 1e-5, rel_all                                   # the filter kernel itself (f32 dot of 64 terms) on every pixel
-    assert float(torch.sqrt(torch.mean((zf.reshape(-1).double() - z_all) ** 2))) <= Z_RMS_TOL
-    out_all = torch.clamp(torch.floor(z_all), 0.0, 255.0).to(torch.uint8)        # trunc(z) for z >= 0, 0 below (Q4)
+    assert float(torch.sqrt(torch.mean((zf.reshape(-1).double() - z_all) ** 2))) <= z_tol
+    out_all = torch.clamp(torch.floor(z_all), 0.0, 255.0).to(torch.uint8)        # trunc(z) for z >= 0, 0 below (Q4); clamp at 255 (hpc/display.c:75-78)
     mism = float((out_all.reshape(size, size) != out).double().mean())
     report["u8_mismatch_frac_all_pixels"] = mism
-    _record("large_parity_%d%s.json" % (size, "" if form == "rank" else "_grid"), report)
+    _record("large_parity_%d%s%s.json" % (size, "" if form == "rank" else "_grid", "" if gain == 3.0 else "_gain%g" % gain), report)
     assert mism <= 1e-4, mism               # only where the f32 / f64 corrections straddle an integer
 
 
