@@ -10,7 +10,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result
 CFLAGS   ?= -O2 -std=gnu11 -Wall -Wextra -fPIC
 
 HIP_SRCS := $(CSRC)/ctx.hip $(CSRC)/affinity.hip $(CSRC)/eigen.hip $(CSRC)/nystroem.hip \
-            $(CSRC)/filter.hip $(CSRC)/pipeline.hip $(CSRC)/comm.hip $(CSRC)/nlm.hip
+            $(CSRC)/filter.hip $(CSRC)/pipeline.hip $(CSRC)/comm.hip $(CSRC)/nlm.hip $(CSRC)/balance.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 CPP_OBJS := $(CSRC)/host_util.o
 C_OBJS   := $(HOST)/png_codec.o

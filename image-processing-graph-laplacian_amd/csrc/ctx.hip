@@ -323,6 +323,8 @@ void glf_options_default(glf_options *opt)
     opt->filter_mode = GLF_FILTER_REFERENCE;
     opt->filter_beta = 1.5f;
     opt->skip_exact_zeros = 0; // evaluate every entry, as the reference does
+    opt->sampling = GLF_SAMPLING_UNIFORM; // hpc/sampling.c:6-23 (the PoC's default too: python/image_processing.py:249)
+    opt->sampling_seed = 1;
 }
 
 void glf_host_free(void *ptr) { std::free(ptr); }

@@ -5,6 +5,8 @@
 // 4 N ld + N bytes each.
 #include "glf_internal.hpp"
 
+#include <algorithm>
+
 namespace glf {
 
 // partial[blk][j] = sum_{pix in blk} Phi[pix][j] * y[pix]
@@ -66,6 +68,55 @@ int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0
     GLF_TRY(part.alloc(ctx, (size_t)nblk * ld));
     hipLaunchKernelGGL(k_phi_t_y, dim3(nblk), dim3(256), 0, ctx->stream, d_phi, d_img, pix0, pix1, ld, part.p);
     hipLaunchKernelGGL(k_cols_sum, dim3(ld), dim3(256), 0, ctx->stream, part.p, nblk, ld, d_c);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GLF_OK;
+}
+
+// partial[blk][i][j] = sum over the pixels of block blk of Phi[px][i] Phi[px][j] (blocks stride the range): the Gram matrix of
+// the extended eigenvectors, which are not orthonormal -- what sits between the factors of the PoC's sharpening filter
+// (python/image_processing.py:231-235). f32 products, f64 across chains of 32.
+__global__ __launch_bounds__(256) void k_phi_gram(const float *__restrict__ phi, int64_t pix0, int64_t pix1, unsigned ld,
+                                                   double *__restrict__ partial)
+{
+    extern __shared__ float tile[]; // [64 pixels][ld]
+    const unsigned npair = ld * ld, e0 = blockIdx.y * 4096u; // this workgroup's 4096 pairs (i, j): 16 per thread
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int64_t base = pix0 + (int64_t)blockIdx.x * 64; base < pix1; base += (int64_t)gridDim.x * 64) {
+        const int npx = (int)((pix1 - base) < 64 ? (pix1 - base) : 64);
+        __syncthreads();
+        for (unsigned e = threadIdx.x; e < 64 * ld; e += 256) tile[e] = e < (unsigned)npx * ld ? phi[(size_t)base * ld + e] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned e = e0 + q * 256 + threadIdx.x;
+            if (e < npair) {
+                const unsigned i = e / ld, j = e % ld;
+                float a = 0.f;
+                for (int r = 0; r < 64; ++r) a = fmaf(tile[r * ld + i], tile[r * ld + j], a);
+                acc[q] += (double)a;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const unsigned e = e0 + q * 256 + threadIdx.x;
+        if (e < npair) partial[(size_t)blockIdx.x * npair + e] = acc[q];
+    }
+}
+
+// d_G[ld][ld] (f64) = Phi^T Phi over the pixels [pix0, pix1) of this rank
+int phi_gram(glf_ctx *ctx, const float *d_phi, int64_t pix0, int64_t pix1, unsigned ld, double *d_G)
+{
+    if (!valid_ld(ld) || pix0 > pix1) return set_error(ctx, GLF_ERR_INVALID, "phi_gram: ld=%u", ld);
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(512, ceil_div(pix1 - pix0, 64)));
+    DevBuf<double> part;
+    GLF_TRY(part.alloc(ctx, (size_t)nblk * ld * ld));
+    hipLaunchKernelGGL(k_phi_gram, dim3(nblk, (unsigned)ceil_div((int64_t)ld * ld, 4096)), dim3(256), 64 * ld * sizeof(float), ctx->stream, d_phi,
+                       pix0, pix1, ld, part.p);
+    hipLaunchKernelGGL(k_cols_sum, dim3(ld * ld), dim3(256), 0, ctx->stream, part.p, nblk, ld * ld, d_G);
     GLF_LAUNCH_CHECK(ctx);
     GLF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GLF_OK;

@@ -386,6 +386,7 @@ int permute_rows(glf_ctx *ctx, const float *d_in, float *d_out, int64_t N, unsig
 // filter.hip
 int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0, int64_t pix1, unsigned m,
             unsigned ld, double *d_c);
+int phi_gram(glf_ctx *ctx, const float *d_phi, int64_t pix0, int64_t pix1, unsigned ld, double *d_G); // Phi^T Phi (f64 [ld][ld])
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1,
                  unsigned m, unsigned ld, const float *d_w, float gain, float ysub, uint8_t *d_out, float *d_zf,
                  float *d_corr = nullptr);

@@ -93,6 +93,33 @@ int glf_random_vectors(double *X0, unsigned p, unsigned m, uint64_t seed)
     return GLF_OK;
 }
 
+// The PoC's random sampler (python/sampling/random.py:8-16): draw until `*sample_size` distinct pixels are there, sort.
+int glf_RandomSampling(int width, int height, unsigned *sample_size, unsigned **sample_indices, uint64_t seed)
+{
+    if (!sample_size || !sample_indices || width <= 0 || height <= 0) return GLF_ERR_INVALID;
+    const uint64_t N = (uint64_t)width * (uint64_t)height;
+    const unsigned want = *sample_size;
+    *sample_indices = nullptr;
+    if (want == 0 || want > N) return GLF_ERR_INVALID;
+    std::vector<uint8_t> taken(N, 0);
+    Xoshiro256ss rng(0xA11CE5EEDull ^ seed);
+    unsigned have = 0;
+    while (have < want) {
+        const uint64_t px = rng.next() % N;
+        if (!taken[px]) {
+            taken[px] = 1;
+            ++have;
+        }
+    }
+    unsigned *idx = static_cast<unsigned *>(std::malloc(sizeof(unsigned) * want));
+    if (!idx) return GLF_ERR_NOMEM;
+    unsigned k = 0;
+    for (uint64_t px = 0; px < N; ++px)
+        if (taken[px]) idx[k++] = (unsigned)px;
+    *sample_indices = idx;
+    return GLF_OK;
+}
+
 // Synthetic noisy benchmark image: smooth low-frequency shading +
 // 64-px two-level checker + one diagonal edge, scaled into [40, 215], plus
 // i.i.d. Gaussian noise sigma = 20 (Box-Muller), rounded and clipped to uint8.

@@ -55,7 +55,8 @@ static NlmMask nlm_mask()
     return m;
 }
 
-__device__ __forceinline__ int nlm_reflect(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - i - 1 : i); } // np.pad 'symmetric'
+// np.pad 'symmetric', one reflection: exact for n >= NLM_R = 3 (smaller images are refused at the entry points, pipeline.hip)
+__device__ __forceinline__ int nlm_reflect(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - i - 1 : i); }
 
 // the 49 weighted patch values of pixel (r, c)
 __device__ __forceinline__ void nlm_patch(const uint8_t *__restrict__ img, int width, int height, int r, int c, const NlmMask &G,

@@ -153,6 +153,8 @@ int glf_ComputeAffinityMatrices(glf_ctx *ctx, glf_mat *K_A, glf_mat *K_B, const 
 {
     if (!ctx || !K_B || !d_img || width <= 0 || height <= 0) return GLF_ERR_INVALID;
     if (kernel < GLF_KERNEL_BILATERAL || kernel > GLF_KERNEL_NLM) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", kernel);
+    if (kernel == GLF_KERNEL_NLM && (width < 3 || height < 3)) // (nlm.hip reflects an out-of-image patch index once: valid from 3 pixels on)
+        return set_error(ctx, GLF_ERR_UNSUPPORTED, "non-local-means kernel: the image must be at least 3 x 3 pixels (%d x %d)", width, height);
     GLF_ENTER(ctx);
     const unsigned p = sample_size;
     SampleTables tb;
@@ -470,6 +472,8 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         opt = *opt_in;
     }
     if (opt.kernel < GLF_KERNEL_BILATERAL || opt.kernel > GLF_KERNEL_NLM) return set_error(ctx, GLF_ERR_INVALID, "kernel %d", opt.kernel);
+    if (opt.kernel == GLF_KERNEL_NLM && (width < 3 || height < 3))
+        return set_error(ctx, GLF_ERR_UNSUPPORTED, "non-local-means kernel: the image must be at least 3 x 3 pixels (%d x %d)", width, height);
     if (opt.filter_mode < GLF_FILTER_REFERENCE || opt.filter_mode > GLF_FILTER_SHARPEN) return set_error(ctx, GLF_ERR_INVALID, "filter_mode %d", opt.filter_mode);
     // f(Pi), the gain and the y term of the filter z = ysub' y + gain Phi f(Pi) Phi^T y:
     //   reference: z = y + gain Phi Pi^k Phi^T y (MatPow is a no-op there, hpc/utils.c:721 => k = 1);
@@ -497,7 +501,8 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     unsigned p = opt.num_samples ? opt.num_samples : (unsigned)((double)N * opt.sample_frac);
     unsigned *h_idx = nullptr;
     {
-        int rc = glf_Sampling(width, height, &p, &h_idx);
+        int rc = opt.sampling == GLF_SAMPLING_RANDOM ? glf_RandomSampling(width, height, &p, &h_idx, opt.sampling_seed)
+                                                       : glf_Sampling(width, height, &p, &h_idx);
         if (rc != GLF_OK || p < 2) {
             std::free(h_idx);
             return set_error(ctx, GLF_ERR_INVALID, "sampling failed (requested %u samples on %dx%d)", p, width, height);
@@ -511,6 +516,8 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     unsigned m = opt.num_eigvals;
     if (m == 0 || m >= p) m = p - 1;
     const bool wide = m > PANEL_COLS; // more than 256 eigenpairs (the reference default m = p - 1): 256-column panels, see below
+    if (wide && opt.filter_mode == GLF_FILTER_SHARPEN) // (its Gram matrix Phi^T Phi would couple the panels)
+        return set_error(ctx, GLF_ERR_UNSUPPORTED, "the sharpening filter takes at most %u eigenpairs (%u asked for)", PANEL_COLS, m);
     if (wide && cap) return set_error(ctx, GLF_ERR_UNSUPPORTED, "glf_capture with more than 256 eigenpairs");
     const unsigned ld = wide ? PANEL_COLS : ld_for(m);
     const unsigned p32 = (unsigned)round_up(p, VEC_PAD);
@@ -759,6 +766,30 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         if (cap && cap->h_c) std::memcpy(cap->h_c, hc.data(), sizeof(double) * ld);
         std::vector<float> hw(ld, 0.f);
         for (unsigned j = 0; j < m; ++j) hw[j] = (float)(filter_weight(lam[j]) * hc[j]);
+        if (opt.filter_mode == GLF_FILTER_SHARPEN) {
+            // (1 + beta) W^2 y - beta W^3 y with W = Phi L Phi^T applied factor by factor as the PoC does
+            // (python/image_processing.py:231-235): the extended eigenvectors are not orthonormal, so G = Phi^T Phi sits
+            // between the factors -- z = Phi w, w = (1 + beta) L G L c - beta L G L G L c, L = 1 - mu, c = Phi^T y
+            DevBuf<double> G;
+            GLF_TRY(G.alloc(ctx, (size_t)ld * ld));
+            GLF_TRY(phi_gram(ctx, phi_base, pix0, pix1, ld, G.p));
+            GLF_TRY(allreduce_f64(ctx, G.p, (size_t)ld * ld));
+            std::vector<double> hG((size_t)ld * ld), t(m), u(m), v(m);
+            GLF_HIP(ctx, hipMemcpyAsync(hG.data(), G.p, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, st));
+            GLF_HIP(ctx, hipStreamSynchronize(st));
+            const double beta = (double)opt.filter_beta;
+            auto LG = [&](const std::vector<double> &x, std::vector<double> &y) { // y = L (G x)
+                for (unsigned i = 0; i < m; ++i) {
+                    double a = 0.0;
+                    for (unsigned j = 0; j < m; ++j) a += hG[(size_t)i * ld + j] * x[j];
+                    y[i] = (1.0 - lam[i]) * a;
+                }
+            };
+            for (unsigned j = 0; j < m; ++j) t[j] = (1.0 - lam[j]) * hc[j];
+            LG(t, u);
+            LG(u, v);
+            for (unsigned j = 0; j < m; ++j) hw[j] = (float)((1.0 + beta) * u[j] - beta * v[j]);
+        }
         GLF_HIP(ctx, hipMemcpyAsync(w.p, hw.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }

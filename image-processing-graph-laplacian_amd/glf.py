@@ -35,6 +35,7 @@ ROWS_NA, ROWS_SAMPLE_FIRST, ROWS_RASTER = 0, 1, 2
 KERNEL_BILATERAL, KERNEL_PHOTOMETRIC, KERNEL_SPATIAL, KERNEL_NLM = 0, 1, 2, 3
 CONTRACT_F32_MFMA, CONTRACT_F16_SPLIT = 1, 2
 FILTER_REFERENCE, FILTER_POC, FILTER_SMOOTH, FILTER_SHARPEN = 0, 1, 2, 3
+SAMPLING_UNIFORM, SAMPLING_RANDOM = 0, 1
 MULTI_RCCL, MULTI_LOOPBACK = 0, 1
 RCCL_ID_BYTES = 128
 
@@ -44,9 +45,9 @@ EXPORTS = [
     "glf_ctx_device_info", "glf_ctx_set_tuning", "glf_ctx_set_comm", "glf_rccl_unique_id", "glf_ctx_set_comm_rccl", "glf_ctx_comm_info", "glf_ctx_comm_counters", "glf_multi_create", "glf_multi_destroy",
     "glf_multi_size", "glf_multi_ctx", "glf_multi_last_error", "glf_multi_image_processing", "glf_shard_rows", "glf_ctx_set_contraction", "glf_malloc", "glf_free", "glf_memcpy_h2d", "glf_memcpy_d2h",
     "glf_memset", "glf_mat_create_dense", "glf_mat_create_diag", "glf_mat_destroy", "glf_mat_get_column", "glf_Sampling",
-    "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_ComputeAffinityMatrices",
+    "glf_host_free", "glf_random_vectors", "glf_synth_image", "glf_RandomSampling", "glf_ComputeAffinityMatrices",
     "glf_ComputeLaplacianMatrix", "glf_InversePowerIteration", "glf_OrthonormaliseVecs", "glf_NormaliseVecs",
-    "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian",
+    "glf_InverseDiagMat", "glf_Nystroem", "glf_Permutation", "glf_ComputeResultFromLaplacian", "glf_Sinkhorn", "glf_SinkhornRows", "glf_Orthogonalisation",
     "glf_options_default", "glf_image_processing", "glf_image_processing_capture", "glf_ctx_debug_violations", "glf_ctx_cached_bytes", "glf_image_processing_batch", "glf_EntireComputation", "glf_read_png", "glf_write_png", "glf_read_png_rgb", "glf_write_png_rgb",
 ]
 
@@ -75,6 +76,7 @@ class Options(C.Structure):
         ("inner_rtol", C.c_double), ("max_outer", C.c_int32), ("seed", C.c_uint64), ("gain", C.c_float),
         ("h_loc", C.c_float), ("h_val", C.c_float), ("kernel", C.c_int32), ("filter_pow", C.c_int32),
         ("filter_mode", C.c_int32), ("skip_exact_zeros", C.c_int32), ("filter_beta", C.c_float),
+        ("sampling", C.c_int32), ("reserved_", C.c_uint32), ("sampling_seed", C.c_uint64),
     ]
 
 
@@ -147,6 +149,18 @@ def Sampling(width, height, sample_size):
     rc = _lib.glf_Sampling(C.c_int(width), C.c_int(height), C.byref(n), C.byref(ptr))
     if rc != OK:
         raise GlfError(rc, "Sampling(%d, %d, %d)" % (width, height, sample_size))
+    idx = np.ctypeslib.as_array(ptr, shape=(max(n.value, 1),))[:n.value].astype(np.uint32).copy()
+    _lib.glf_host_free(ptr)
+    return idx
+
+
+def RandomSampling(width, height, sample_size, seed=1):
+    """python/sampling/random.py:8-16 -> sample_size distinct pixel indices, ascending (the library's own generator)."""
+    n = C.c_uint(sample_size)
+    ptr = C.POINTER(C.c_uint)()
+    rc = _lib.glf_RandomSampling(C.c_int(width), C.c_int(height), C.byref(n), C.byref(ptr), C.c_uint64(seed))
+    if rc != OK:
+        raise GlfError(rc, "RandomSampling(%d, %d, %d)" % (width, height, sample_size))
     idx = np.ctypeslib.as_array(ptr, shape=(max(n.value, 1),))[:n.value].astype(np.uint32).copy()
     _lib.glf_host_free(ptr)
     return idx
@@ -414,6 +428,36 @@ class Context:
         self._native_rank = (rank, size)
         self._check(_lib.glf_ctx_set_comm_rccl(self._ctx, C.c_int(rank), C.c_int(size), buf, C.c_size_t(RCCL_ID_BYTES),
                                                C.c_int(1 if force else 0)), "set_comm_rccl")
+
+    # -- the PoC's balancing steps ------------------------------------------------
+    def Sinkhorn(self, phi, Pi, iterations=100, rows=None):
+        """sinkhorn(phi, Pi), python/image_processing.py:90-107. phi: dense N x m Mat, Pi: diagonal Mat. Returns (r, c) as numpy
+        f64 [N]; with rows = n also W_AB[:n] = diag(r) K diag(c) rows as numpy [n, N] (the PoC's [W_A W_B] for n = m)."""
+        torch = self.torch
+        N = int(phi.rows)
+        r = torch.empty(N, dtype=torch.float64, device=self.device)
+        c = torch.empty(N, dtype=torch.float64, device=self.device)
+        self._check(_lib.glf_Sinkhorn(self._ctx, C.byref(phi), C.byref(Pi), C.c_int(iterations), C.c_void_p(r.data_ptr()),
+                                      C.c_void_p(c.data_ptr())), "Sinkhorn")
+        if rows is None:
+            return r.cpu().numpy(), c.cpu().numpy()
+        out = torch.empty((rows, N), dtype=torch.float64, device=self.device)
+        self._check(_lib.glf_SinkhornRows(self._ctx, C.byref(phi), C.byref(Pi), C.c_void_p(r.data_ptr()), C.c_void_p(c.data_ptr()),
+                                          C.c_int64(0), C.c_int(rows), C.c_void_p(out.data_ptr())), "SinkhornRows")
+        return r.cpu().numpy(), c.cpu().numpy(), out.cpu().numpy()
+
+    def Orthogonalisation(self, A, B):
+        """orthogonalisation(A, B), python/image_processing.py:110-127. A: numpy n x n, B: numpy n x q -> (V [(n + q), n], Pi [n])."""
+        torch = self.torch
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        n, q = A.shape[0], B.shape[1]
+        dA, dB = torch.from_numpy(A).to(self.device), torch.from_numpy(B).to(self.device)
+        dV = torch.empty((n + q, n), dtype=torch.float64, device=self.device)
+        Pi = np.zeros(n, dtype=np.float64)
+        self._check(_lib.glf_Orthogonalisation(self._ctx, C.c_void_p(dA.data_ptr()), C.c_int(n), C.c_void_p(dB.data_ptr()), C.c_int(q),
+                                               C.c_void_p(dV.data_ptr()), Pi.ctypes.data_as(C.c_void_p)), "Orthogonalisation")
+        return dV.cpu().numpy(), Pi
 
     def comm_info(self):
         """What the context's communicator reports: dict(rank, size, backend, rccl_ranks = ncclCommCount)."""

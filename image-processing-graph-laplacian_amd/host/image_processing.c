@@ -5,7 +5,7 @@
  * C-ABI (include/glf.h) through the stage mirror in stages.h.
  *
  *   image_processing -f FILE [-num_eigvals N] [-opti_gs N] [-inv_it_epsilon E]
- *                    [-num_samples P | -sample_frac F] [-fused] [-device D] [-no_approx] [-use_slepc]
+ *                    [-num_samples P | -sample_frac F] [-sampling uniform|random] [-sampling_seed S] [-fused] [-device D] [-no_approx] [-use_slepc]
  *                    [-dump_eigvecs] [-ngpu N [-ngpu_backend rccl|loopback]] [-filter_pow K]
  *                    [-kernel bilateral|photometric|spatial|nlm] [-h_loc X] [-h_val X] [-gain X] [-dump_residual]
  *                    [-filter reference|poc|smooth|sharpen [-sharpen_beta B]] [-color]
@@ -233,6 +233,8 @@ static void fill_options(glf_options *opt, unsigned width, unsigned height)
     opt->opti_gs = GetOptiGramSchmidt();
     opt->epsilon = GetInverseIterationEpsilon();
     opt->kernel = stage_kernel;
+    opt->sampling = stage_sampling;
+    opt->sampling_seed = stage_sampling_seed;
     opt->h_loc = stage_h_loc;
     opt->h_val = stage_h_val;
     opt->gain = stage_gain;
@@ -434,6 +436,16 @@ int main(int argc, char **argv)
         if ((v = opt_value("-h_loc")) && atof(v) > 0.0) stage_h_loc = (float)atof(v);
         if ((v = opt_value("-h_val")) && atof(v) > 0.0) stage_h_val = (float)atof(v);
         if ((v = opt_value("-gain"))) stage_gain = (float)atof(v);
+        if ((v = opt_value("-sampling"))) { /* the PoC's sampler registry, python/sampling/__init__.py:4-9 (the C reference has the grid only) */
+            if (strcmp(v, "uniform") == 0 || strcmp(v, "spatially_uniform") == 0) stage_sampling = GLF_SAMPLING_UNIFORM;
+            else if (strcmp(v, "random") == 0) stage_sampling = GLF_SAMPLING_RANDOM;
+            else {
+                fprintf(stderr, "-sampling %s: expected uniform or random\n", v);
+                FinalizeProgram();
+                return 1;
+            }
+        }
+        if ((v = opt_value("-sampling_seed"))) stage_sampling_seed = strtoull(v, NULL, 10);
         if ((v = opt_value("-kernel"))) { /* bilateral (hpc/affinity.c:121) | photometric | spatial (:119-120) | nlm (python/affinity_methods/NLM.py) */
             if (strcmp(v, "bilateral") == 0) stage_kernel = GLF_KERNEL_BILATERAL;
             else if (strcmp(v, "photometric") == 0) stage_kernel = GLF_KERNEL_PHOTOMETRIC;

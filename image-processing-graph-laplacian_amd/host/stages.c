@@ -56,9 +56,14 @@ int write_png(const char *filename, png_bytep *img_bytes, unsigned int width, un
     return glf_write_png(filename, img_bytes, width, height);
 }
 
+int stage_sampling = GLF_SAMPLING_UNIFORM;      /* -sampling uniform | random (python/sampling/__init__.py:4-9) */
+unsigned long long stage_sampling_seed = 1;
+
 void Sampling(int width, int height, unsigned int *sample_size, unsigned int **sample_indices)
 {
-    if (glf_Sampling(width, height, sample_size, sample_indices) != GLF_OK) {
+    const int rc = stage_sampling == GLF_SAMPLING_RANDOM ? glf_RandomSampling(width, height, sample_size, sample_indices, stage_sampling_seed)
+                                                          : glf_Sampling(width, height, sample_size, sample_indices);
+    if (rc != GLF_OK) {
         *sample_size = 0;
         *sample_indices = NULL;
     }

@@ -17,6 +17,8 @@ typedef glf_mat *Mat;             /* replaces PETSc Mat (MATMPIDENSE / diagonal 
 glf_ctx *glf_world(void);         /* replaces PETSC_COMM_WORLD */
 /* hpc/affinity.c:117-118 and hpc/display.c:73 hard-code 40, 30 and 3.0; these default to the same values */
 extern float stage_h_loc, stage_h_val, stage_gain;
+extern int stage_sampling;       /* GLF_SAMPLING_*: the reference's grid (hpc/sampling.c) or the PoC's random sampler (python/sampling/random.py) */
+extern unsigned long long stage_sampling_seed;
 extern int stage_kernel;         /* GLF_KERNEL_*: the kernel the reference selects by (un)commenting hpc/affinity.c:119-121 */
 
 int InitProgram(int device);      /* hpc/image_processing.c:30-38 */

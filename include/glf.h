@@ -255,6 +255,20 @@ int glf_NormaliseVecs(glf_ctx *ctx, glf_mat *X, double *norms);
 /* Mat InverseDiagMat(Mat x)  hpc/utils.h (hpc/utils.c:559-586) */
 int glf_InverseDiagMat(glf_ctx *ctx, const glf_mat *x, glf_mat *inv);
 
+/* ---- the PoC's balancing steps of the approximated affinity (inactive experiments in the PoC) ----------
+ * sinkhorn(phi, Pi)  python/image_processing.py:90-98: the alternating scalings of K = phi diag(Pi) phi^T, K never formed
+ * (200 products K x = phi (Pi o (phi^T x)) for the PoC's 100 iterations). phi: dense N x m in any row order, Pi: diagonal m;
+ * d_r, d_c: device double[N]. */
+int glf_Sinkhorn(glf_ctx *ctx, const glf_mat *phi, const glf_mat *Pi, int iterations, double *d_r, double *d_c);
+/* :99-102: rows [row0, row0 + nrows) of W_AB = diag(r) K diag(c) into d_out (device double [nrows][N]); the PoC keeps the
+ * first m rows and splits them into W_A = W_AB[:, :m], W_B = W_AB[:, m:] (:103-104). */
+int glf_SinkhornRows(glf_ctx *ctx, const glf_mat *phi, const glf_mat *Pi, const double *d_r, const double *d_c, int64_t row0, int nrows,
+                     double *d_out);
+/* orthogonalisation(A, B)  :110-127: V = [A ; B^T] A^-1/2 phi_Q Pi_Q^-1/2 with Q = A + A^-1/2 B B^T A^-1/2.
+ * d_A: device double n x n (symmetric positive definite), d_B: device double n x q (row-major); d_V: device double
+ * (n + q) x n; h_Pi: HOST double[n], clipped at 1. Dense f64 with a one-workgroup Jacobi eigensolver: n <= 512. */
+int glf_Orthogonalisation(glf_ctx *ctx, const double *d_A, int n, const double *d_B, int q, double *d_V, double *h_Pi);
+
 /* Mat Nystroem(Mat B, Mat phi_A, Mat Pi_A_Inv, unsigned N, unsigned n, unsigned p)  hpc/nystroem.h:3, hpc/nystroem.c:5-69
  * B: KERNEL_B descriptor (L_B). phi (allocated here): N x m, SAMPLE-FIRST rows:
  * [phi_A ; B^T (phi_A Pi_A_Inv)]. */
@@ -304,7 +318,16 @@ typedef struct glf_options {
                                  distance beyond the radius where exp underflows) are skipped in whole tiles;
                                  the output is bit-identical, the work is not -- see glf_stats.*_evaluated. */
     float filter_beta;      /* GLF_FILTER_SHARPEN: 1.5 (python/image_processing.py:231) */
+    int32_t sampling;       /* GLF_SAMPLING_UNIFORM (0): the reference's grid (hpc/sampling.c:6-23); GLF_SAMPLING_RANDOM (1): the PoC's
+                               random sampler (python/sampling/random.py:8-16: num_samples distinct pixels, ascending) -- not a tensor
+                               grid, so the entry-by-entry kernels and a stored L_A run */
+    uint32_t reserved_;
+    uint64_t sampling_seed; /* GLF_SAMPLING_RANDOM: seed of the library's own generator (the PoC draws from an unseeded numpy stream) */
 } glf_options;
+enum { GLF_SAMPLING_UNIFORM = 0, GLF_SAMPLING_RANDOM = 1 };
+/* python/sampling/random.py:8-16: *sample_size distinct pixel indices drawn uniformly (xoshiro256** seeded with `seed`), sorted
+ * ascending; malloc'd like glf_Sampling's. */
+int glf_RandomSampling(int width, int height, unsigned *sample_size, unsigned **sample_indices, uint64_t seed);
 void glf_options_default(glf_options *opt);
 
 typedef struct glf_stats {

@@ -286,3 +286,78 @@ def nystroem_rows(img, idx, alpha, phi_A, eigvals, row0, row1, prm=None):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+# ---- the PoC's alternative filters and balancing steps, numpy restatements -----------------------------------
+# python/image_processing.py: nystroem :69-86, sinkhorn :90-107, orthogonalisation :110-127, smoothing_matrix :151-194,
+# smoothing :197-219, sharpening :222-241. Dense fp64 on small images only (the PoC itself forms N x N matrices in
+# smoothing_matrix); pinned against the PoC's own outputs in tests/golden/f4.npz (tools/gen_golden_f4.py).
+
+def poc_nystroem(K_A, K_B):
+    """:69-86 -- SVD of the symmetric K_A (descending Pi), phi = [phi_A ; K_B^T phi_A / Pi] in sample-first row order."""
+    phi_A, Pi, _ = np.linalg.svd(K_A)
+    return np.concatenate((phi_A, K_B.T @ (phi_A * (1.0 / Pi)))), Pi
+
+
+def poc_sinkhorn_scalings(phi, Pi, iterations=100):
+    """:93-98 -- the alternating scalings r, c (length = rows of phi) of K = phi diag(Pi) phi^T, never forming K."""
+    r = np.ones(phi.shape[0])
+    c = r
+    for _ in range(iterations):
+        c = np.nan_to_num(1.0 / (phi @ (Pi * (phi.T @ r))))
+        r = np.nan_to_num(1.0 / (phi @ (Pi * (phi.T @ c))))
+    return r, c
+
+
+def poc_sinkhorn(phi, Pi, iterations=100):
+    """:90-107 -- W_AB[i, :] = r_i phi_i Pi (phi c)^T for the first n rows i (n = columns of phi: the sample rows when all
+    p pairs are kept), split into W_A (n x n) and W_B (n x rest)."""
+    M, n = phi.shape
+    r, c = poc_sinkhorn_scalings(phi, Pi, iterations)
+    W_AB = ((r[:n, None] * phi[:n]) * Pi) @ (phi * c[:, None]).T
+    return W_AB[:, :n], W_AB[:, n:M]
+
+
+def poc_orthogonalisation(A, B):
+    """:110-127 -- V = [A ; B^T] A^-1/2 phi_Q Pi_Q^-1/2 with Q = A + A^-1/2 B B^T A^-1/2; eigenvalues clipped at 1."""
+    phi, Pi, _ = np.linalg.svd(A)
+    A_sqrt_inv = (phi * (1.0 / np.sqrt(Pi))) @ phi.T
+    Q = A + A_sqrt_inv @ B @ B.T @ A_sqrt_inv
+    phi_Q, Pi_Q, _ = np.linalg.svd(Q)
+    V = np.concatenate((A, B.T)) @ A_sqrt_inv @ phi_Q @ np.diag(1.0 / np.sqrt(Pi_Q))
+    return V, np.minimum(Pi_Q, 1.0)
+
+
+def poc_smoothing_matrix(idx, phi, Pi):
+    """:151-194 -- W = I + alpha (K - D) of the dense K = phi diag(Pi) phi^T, eigenpairs of its leading p x p block W_A
+    (descending) extended through W_B and brought into raster order."""
+    K = (phi * Pi) @ phi.T
+    D = K.sum(axis=1)
+    alpha = 1.0 / D.mean()
+    W = np.identity(K.shape[0]) + alpha * (K - np.diag(D))
+    p = len(idx)
+    L, phi_A = np.linalg.eigh(W[:p, :p])
+    L, phi_A = L[::-1], phi_A[:, ::-1]
+    V = np.concatenate((phi_A, W[:p, p:].T @ (phi_A * (1.0 / L))))
+    return permutation(V.T, idx).T, L
+
+
+def poc_smoothing_filter(y, V, L):
+    """:213 -- z = V diag(L) V^T y."""
+    return (V @ (L * (V.T @ np.asarray(y, dtype=np.float64).reshape(-1)))).reshape(np.shape(y))
+
+
+def poc_sharpening_filter(y, V, L, beta=1.5):
+    """:231-235 -- z = (1 + beta) W^2 y - beta W^3 y with W = V diag(L) V^T applied factor by factor (V is NOT orthonormal:
+    the Gram matrix V^T V sits between the factors)."""
+    yv = np.asarray(y, dtype=np.float64).reshape(-1)
+    w2 = V @ (L * (V.T @ (V @ (L * (V.T @ yv)))))
+    w3 = V @ (L * (V.T @ w2))
+    return ((1.0 + beta) * w2 - beta * w3).reshape(np.shape(y))
+
+
+def sharpening_weights(G, L, c, beta=1.5):
+    """The same filter from the m x m Gram matrix G = V^T V and c = V^T y: z = V w with
+    w = (1 + beta) L G L c - beta L G L G L c (what the HIP path evaluates: filter.hip, GLF_FILTER_SHARPEN)."""
+    u = L * (G @ (L * c))
+    return (1.0 + beta) * u - beta * (L * (G @ u))

@@ -161,3 +161,15 @@ def test_png_rgb_codec(tmp_path):
     assert glf._lib.glf_write_png_rgb(path.encode(), rows, C.c_uint(53), C.c_uint(37)) == 0
     np.testing.assert_array_equal(glf.read_png_rgb(path), img)
     np.testing.assert_array_equal(np.array(Image.open(path)), img)
+
+
+def test_random_sampler_contract():
+    """The PoC's random sampler (python/sampling/random.py:8-16) through the C-ABI: exactly the requested number of distinct
+    pixel indices, ascending, reproducible per seed, different between seeds; degenerate requests are refused."""
+    a = glf.RandomSampling(64, 48, 200, seed=7)
+    assert a.size == 200 and np.all(np.diff(a.astype(np.int64)) > 0) and a.max() < 64 * 48
+    np.testing.assert_array_equal(a, glf.RandomSampling(64, 48, 200, seed=7))
+    assert not np.array_equal(a, glf.RandomSampling(64, 48, 200, seed=8))
+    assert glf.RandomSampling(8, 8, 64, seed=1).size == 64                      # every pixel
+    with pytest.raises(glf.GlfError):
+        glf.RandomSampling(8, 8, 65)

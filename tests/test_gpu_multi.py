@@ -106,3 +106,15 @@ def test_loopback_two_ranks_nlm_kernel():
     opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
     opt.kernel, opt.h_val = glf.KERNEL_NLM, 3.0
     _check(img, opt, 2, glf.MULTI_LOOPBACK, [0, 0])
+
+
+def test_rccl_two_gpus_match_single_context():
+    """N > 1 over real RCCL (ncclCommInitAll, one rank thread per GPU): skipped on a one-GPU box -- the driver's multi-GPU node
+    runs it. Same comparison as the loopback tests: the sharded result against one context on the whole image."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    img = glf.synth_image(1024, 1024, seed=5)
+    opt = glf.default_options(num_samples=int(1024 * 1024 * 0.005), num_eigvals=64, epsilon=0.1)
+    infos = _check(img, opt, 2, glf.MULTI_RCCL, [0, 1])
+    assert infos[0]["row1"] == 512 and infos[1]["row0"] == 512

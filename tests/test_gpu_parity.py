@@ -690,6 +690,42 @@ def test_nlm_kernel_end_to_end(ctx, w, h, ns, m):
     _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info, eigvals=True, prm=prm)
 
 
+def test_random_sampler_end_to_end(ctx):
+    """glf_options.sampling = GLF_SAMPLING_RANDOM (the PoC's other sampler, python/sampling/random.py; `-sampling random` in the
+    host program): the whole path on a non-grid sample set -- entry-by-entry kernels, stored L_A -- against the oracle's
+    stages fed the same indices."""
+    w, h, ns, m, eps = 96, 80, 70, 8, 1e-3
+    img = glf.synth_image(w, h, seed=29)
+    opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
+    opt.sampling, opt.sampling_seed = glf.SAMPLING_RANDOM, 5
+    out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
+    idx = glf.RandomSampling(w, h, ns, seed=5)
+    assert info["p"] == ns and info["nystroem_path"] == 0 and info["matvec_path"] == 0
+    KA, _ = orc.affinity(img, idx, want_KB=False)
+    D = orc.degree(img, idx)
+    LA, alpha = orc.laplacian(KA, D)
+    assert info["alpha"] == pytest.approx(alpha, rel=2e-6)
+    X0 = glf.random_vectors(ns, m, 1)
+    vecs, vals, st = orc.inverse_power_iteration(LA, m, X0, epsilon=eps, inner_rtol=1e-5)
+    np.testing.assert_allclose(info["eigvals"], vals, atol=2e-4)
+    phi = orc.permutation(orc.nystroem(img, idx, alpha, vecs, vals), idx)
+    zref, out_ref = orc.result_from_laplacian(img, phi, vals, gain=3.0)
+    np.testing.assert_allclose(zf.cpu().numpy(), zref.reshape(h, w), rtol=0, atol=2e-2)
+    assert np.mean(np.abs(out.cpu().numpy().astype(int) - out_ref.reshape(h, w).astype(int)) <= 1) >= 0.99
+
+
+def test_nlm_kernel_refuses_images_below_3x3(ctx):
+    """The 7 x 7 patches are padded symmetrically (python/affinity_methods/NLM.py:17); nlm.hip reflects an index once, which
+    is exact from 3 pixels on -- a smaller image is refused instead of reading past the image."""
+    opt = glf.default_options(num_samples=2, num_eigvals=1, epsilon=0.1)
+    opt.kernel, opt.h_val = glf.KERNEL_NLM, 3.0
+    for w, h in ((2, 9), (9, 2)):
+        img = glf.synth_image(w, h, seed=1)
+        with pytest.raises(glf.GlfError) as e:
+            ctx.image_processing(ctx.to_device(img), opt)
+        assert e.value.status == glf.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
 @pytest.mark.parametrize("ns,m", [(600, 0), (600, 300), (300, 257)])
 def test_more_than_256_eigenpairs_end_to_end(ctx, ns, m, paths, monkeypatch):
@@ -836,10 +872,12 @@ def test_batch_throughput_mode_is_bit_identical_to_single_calls(ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["smooth", "sharpen"])
 def test_smoothing_and_sharpening_filters(ctx, png, mode):
-    """f4: the PoC's `smoothing` (z = W y) and `sharpening` (z = (1 + beta) W^2 y - beta W^3 y, beta = 1.5)
-    (python/image_processing.py:197-241) in spectral form on the eigenpairs of this path: W = I - L has the eigenvalues
-    1 - mu with the same vectors, so z = Phi f(1 - mu) Phi^T y. Checked against the fp64 oracle fed the same eigenpairs
-    (orc.result_from_laplacian computes y + Phi f Phi^T y; the y term is taken out again)."""
+    """f4: the PoC's `smoothing` (z = W y) and `sharpening` (z = (1 + beta) W^2 y - beta W^3 y, beta = 1.5) filters
+    (python/image_processing.py:213, :231-235) with W = Phi L Phi^T on the eigenpairs of this path (L = 1 - mu: W = I - L_A's
+    extension). The PoC applies W factor by factor -- its vectors are Nystroem-extended, not orthonormal -- and so does the
+    HIP path (the Gram matrix Phi^T Phi between the factors, filter.hip). Checked against the numpy restatements of the PoC's
+    two filter lines (oracle.poc_*_filter, themselves pinned to the PoC's outputs in tests/test_oracle_golden.py) fed the
+    GPU's own Phi and eigenvalues; a result that assumed Phi^T Phi = I would fail the sharpening case."""
     img = np.ascontiguousarray(png("test.png"))
     if img.ndim == 3:
         img = np.ascontiguousarray(img[:, :, 0])
@@ -851,12 +889,14 @@ def test_smoothing_and_sharpening_filters(ctx, png, mode):
     out, zf, info = ctx.image_processing(d_img, opt, want_float=True, capture=True)
     out, zf = out.cpu().numpy(), zf.cpu().numpy()
     lam = np.asarray(info["eigvals"], dtype=np.float64)
-    s1 = 1.0 - lam
-    f = s1 if mode == "smooth" else (1.0 + beta) * s1 ** 2 - beta * s1 ** 3
-    phi = info["capture"]["phi"].cpu().numpy().astype(np.float64)   # [N, ld] raster rows as the filter kernel read them
     m = lam.size
-    zref, _ = orc.result_from_laplacian(img, np.ascontiguousarray(phi[:, :m].T), f, gain=1.0)
-    zref = zref.reshape(h, w) - img.astype(np.float64)   # no y term in these filters
+    phi = info["capture"]["phi"].cpu().numpy().astype(np.float64)[:, :m]   # [N, m] raster rows as the filter kernel read them
+    y = img.astype(np.float64)
+    zref = orc.poc_smoothing_filter(y, phi, 1.0 - lam) if mode == "smooth" else orc.poc_sharpening_filter(y, phi, 1.0 - lam, beta)
+    if mode == "sharpen":   # the orthonormal shortcut f(s) = (1 + beta) s^2 - beta s^3 is a different filter on these vectors
+        s1 = 1.0 - lam
+        z_short = (phi @ (((1.0 + beta) * s1 ** 2 - beta * s1 ** 3) * (phi.T @ y.reshape(-1)))).reshape(h, w)
+        assert np.max(np.abs(z_short - zref)) > 20 * 2e-3 * max(1.0, np.max(np.abs(zref)))
     ref8 = np.clip(zref, 0.0, 255.0).astype(np.uint8)
     assert np.max(np.abs(zf.astype(np.float64) - zref)) <= 2e-3 * max(1.0, np.max(np.abs(zref)))
     assert np.mean(out == ref8) >= 0.999 and np.max(np.abs(out.astype(int) - ref8.astype(int))) <= 1
@@ -864,6 +904,40 @@ def test_smoothing_and_sharpening_filters(ctx, png, mode):
     tv = lambda a: float(np.abs(np.diff(a.astype(np.float64), axis=1)).sum())
     if mode == "smooth":
         assert tv(zf) < tv(img)
+
+
+@pytest.mark.gpu
+def test_sinkhorn_and_orthogonalisation_against_the_poc(ctx, golden):
+    """f4: the PoC's balancing steps on the device (csrc/balance.hip). sinkhorn (python/image_processing.py:90-107): the 100
+    alternating scalings as 200 products Phi (Pi o (Phi^T x)) on the resident Phi / Pi, then the rows of W_AB; orthogonalisation
+    (:110-127) on the PoC's own W_A, W_B. Against the PoC's outputs (tests/golden/f4.npz) and the numpy restatements."""
+    g = golden("f4.npz")
+    phi64, Pi64 = g["phi"], g["Pi"]                      # [1024, 9] sample-first rows, 9 eigenvalues of K_A
+    n = Pi64.size
+    phi, Pi = ctx.dense_from_numpy(phi64.astype(np.float32)), ctx.diag_from_numpy(Pi64.astype(np.float32))
+    r, c, W_AB = ctx.Sinkhorn(phi, Pi, iterations=100, rows=n)
+    # (Phi and Pi travel as f32, the PoC holds them in f64: compare with the restatement on the SAME rounded inputs tightly,
+    # with the PoC's own outputs at f32 input accuracy)
+    r_ref, c_ref = orc.poc_sinkhorn_scalings(phi64.astype(np.float32).astype(np.float64), Pi64.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(r, r_ref, rtol=1e-9)
+    np.testing.assert_allclose(c, c_ref, rtol=1e-9)
+    np.testing.assert_allclose(W_AB[:, :n], g["W_A"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(W_AB[:, n:], g["W_B"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(W_AB.sum(axis=1), 1.0, rtol=1e-5)          # balanced
+    ctx.destroy(phi, Pi)
+    V, P = ctx.Orthogonalisation(g["W_A"], g["W_B"])
+    np.testing.assert_allclose(P, g["Pi_orth"], rtol=1e-9)
+    np.testing.assert_allclose(np.abs(V), np.abs(g["V_orth"]), rtol=0, atol=1e-8 * np.abs(g["V_orth"]).max())
+    np.testing.assert_allclose(V.T @ V, np.identity(n), atol=1e-9)
+    # a larger, odd-sized case against the restatement (the tournament ordering of the Jacobi sweeps has a bye then)
+    rng = np.random.RandomState(5)
+    X = rng.rand(37, 37)
+    A = X @ X.T + 37 * np.identity(37)
+    B = rng.rand(37, 211)
+    V2, P2 = ctx.Orthogonalisation(A, B)
+    V2_ref, P2_ref = orc.poc_orthogonalisation(A, B)
+    np.testing.assert_allclose(P2, P2_ref, rtol=1e-10)
+    np.testing.assert_allclose(np.abs(V2), np.abs(V2_ref), rtol=0, atol=1e-9 * np.abs(V2_ref).max())
 
 
 @pytest.mark.gpu

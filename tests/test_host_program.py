@@ -53,6 +53,25 @@ def test_image_processing_on_test_png(tmp_path, png, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-fused"]])
+def test_sampling_random_flag(tmp_path, png, extra):
+    """-sampling random (the PoC's sampler registry, python/sampling/__init__.py:4-9; the C reference has the grid only): exactly the
+    requested number of samples, stage by stage and through the whole-path call; a second run with the same seed reproduces
+    the output, another seed does not; an unknown sampler is refused."""
+    outs = []
+    for seed in ("3", "3", "4"):
+        r = _run(["-f", TEST_PNG, "-num_eigvals", "8", "-num_samples", "90", "-sampling", "random", "-sampling_seed", seed] + extra, str(tmp_path))
+        assert r.returncode == 0, r.stderr.decode()
+        assert "Sample size: 90" in r.stdout.decode()
+        outs.append(glf.read_png(str(tmp_path / "results" / "output.png")))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0], outs[2])
+    assert psnr(outs[0], png("test.png")) >= 30.0          # a filtered version of the input, not noise
+    r = _run(["-f", TEST_PNG, "-sampling", "hexagonal"], str(tmp_path))
+    assert r.returncode == 1 and b"expected uniform or random" in r.stderr
+
+
+@pytest.mark.gpu
 def test_eigenvector_dumps(tmp_path, png):
     """-dump_eigvecs: the diagnostics of the reference's commented tail (hpc/image_processing.c:252-260)."""
     r = _run(["-f", TEST_PNG, "-num_eigvals", "8", "-dump_eigvecs"], str(tmp_path))

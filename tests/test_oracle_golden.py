@@ -313,3 +313,32 @@ def test_nlm_kernel_against_the_poc(golden):
         D = K.sum(1)
         LA, alpha = orc.laplacian(KA, D)
         np.testing.assert_allclose(orc.laplacian_rows(img, idx, D, alpha, 2, 5, prm=prm), LA[2:5], rtol=1e-13, atol=1e-300)
+
+
+def test_poc_alternative_filters_and_balancing(golden):
+    """the numpy restatements of the PoC's sinkhorn / orthogonalisation / smoothing_matrix / smoothing /
+    sharpening (python/image_processing.py:90-241) against the PoC's own outputs on the 32 x 32 image (tests/golden/f4.npz,
+    tools/gen_golden_f4.py). Singular vectors are compared up to sign."""
+    g = golden("f4.npz")
+    phi, Pi = orc.poc_nystroem(g["K_A"], g["K_B"])
+    np.testing.assert_allclose(Pi, g["Pi"], rtol=1e-10)
+    np.testing.assert_allclose(np.abs(phi), np.abs(g["phi"]), rtol=0, atol=1e-9 * np.abs(g["phi"]).max())
+    W_A, W_B = orc.poc_sinkhorn(g["phi"], g["Pi"])
+    np.testing.assert_allclose(W_A, g["W_A"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(W_B, g["W_B"], rtol=1e-9, atol=1e-12)
+    # doubly stochastic in the PoC's sense: rows of [W_A W_B] sum to 1 after 100 scalings
+    np.testing.assert_allclose(np.concatenate((W_A, W_B), axis=1).sum(axis=1), 1.0, rtol=1e-6)
+    V, P = orc.poc_orthogonalisation(g["W_A"], g["W_B"])
+    np.testing.assert_allclose(P, g["Pi_orth"], rtol=1e-8)
+    np.testing.assert_allclose(np.abs(V), np.abs(g["V_orth"]), rtol=0, atol=1e-7 * np.abs(g["V_orth"]).max())
+    np.testing.assert_allclose(V.T @ V, np.identity(V.shape[1]), atol=1e-8)      # what the step is for
+    Vs, Ls = orc.poc_smoothing_matrix(g["idx"], g["phi"], g["Pi"])
+    np.testing.assert_allclose(Ls, g["L_smooth"], rtol=1e-9)
+    np.testing.assert_allclose(np.abs(Vs), np.abs(g["V_smooth"]), rtol=0, atol=1e-8 * np.abs(g["V_smooth"]).max())
+    y = g["img"].astype(np.float64)
+    np.testing.assert_allclose(orc.poc_smoothing_filter(y, g["V_smooth"], g["L_smooth"]), g["z_smooth"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(orc.poc_sharpening_filter(y, g["V_smooth"], g["L_smooth"]), g["z_sharp"], rtol=1e-9, atol=1e-8)
+    # the Gram form of the sharpening filter (what the HIP path evaluates) is the same filter
+    V_, L_ = g["V_smooth"], g["L_smooth"]
+    w = orc.sharpening_weights(V_.T @ V_, L_, V_.T @ y.reshape(-1))
+    np.testing.assert_allclose((V_ @ w).reshape(y.shape), g["z_sharp"], rtol=1e-9, atol=1e-8)
