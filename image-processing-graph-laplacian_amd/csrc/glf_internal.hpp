@@ -32,6 +32,8 @@ struct glf_tuning {
     int mv_path = 0;             // MV_PATH: 0 auto, 1 grid (L_A applied in factored form), 2 dense (stored L_A), 3 rank (factored, rank-R photometric table)
     int rowpass = 0;             // ROWPASS: row pass of the Nystroem passes: 0 / rt = row-tile form, 1 / v1 = one image row per wave
     int rowpass_op = 0;          // ROWPASS_OP: row pass of the L_A sweeps: 0 / v1, 1 / rt
+    bool sweep_samples = false;  // SWEEP_COLPASS: rank-form L_A sweeps: false / segments = k_rank_colpass on the samples, true / samples = k_rank_samples
+    int colpass = 0;             // COLPASS: rank-form column pass: 0 / ws = waves split into forming and contracting roles, 1 / v1 = every wave does both
     bool nys_no_lut = false;     // NYS_NO_LUT: direct Nystroem kernel generates entries with v_exp_f32 instead of LDS tables
     bool no_ecr = false;         // NO_ECR: column pass reads the per-column Ec fragment table instead of the compact one
     bool gs_seq = false;         // GS=seq: Gram-Schmidt as the column-by-column sweep instead of the Gram-matrix form

@@ -427,12 +427,15 @@ def test_call_sequence_of_the_recorded_fault(golden, png, mode, pool, monkeypatc
 _FAULT_SEQ = {}
 
 
+@pytest.mark.parametrize("sweeps,colpass", [("segments", "ws"), ("segments", "v1"), ("samples", "ws")])
 @pytest.mark.parametrize("name,ns,m,eps", [("ragged", 20, 5, 0.1), ("cat50", 50, 53, 0.1), ("test", 100, 16, 0.1), ("test", 400, 70, 0.1)])
-def test_end_to_end_with_rank_forms_forced(ctx, golden, png, name, ns, m, eps):
+def test_end_to_end_with_rank_forms_forced(ctx, golden, png, name, ns, m, eps, sweeps, colpass):
     """The rank form of the grid-factored contractions (photometric table as a rank-R expansion, T' formed in LDS: the
     default from 1024-pixel-wide images on) forced on the small reference images, for the Nystroem extension and for the
-    L_A sweeps of the eigen-solve, against the fp64 oracle."""
-    ctx.set_tuning(NYS_PATH="rank", DEG_PATH="grid", MV_PATH="rank")
+    L_A sweeps of the eigen-solve, against the fp64 oracle. colpass: the column pass with the waves' roles split (k_rank_colpass_ws,
+    the default) or every wave forming and contracting (k_rank_colpass); sweeps: the L_A sweeps through that column pass with
+    the samples as pixels (default) or through k_rank_samples (the term index contracted on the target side)."""
+    ctx.set_tuning(NYS_PATH="rank", DEG_PATH="grid", MV_PATH="rank", SWEEP_COLPASS=sweeps, COLPASS=colpass)
     img, _ = _images(golden, png)[name]
     out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
                                          want_float=True)
