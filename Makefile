@@ -17,7 +17,7 @@ C_OBJS   := $(HOST)/png_codec.o
 
 all: $(PKG)/libglf.so $(PKG)/image_processing oracle
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/glf_internal.hpp $(CSRC)/nystroem_grid.inc $(CSRC)/nystroem_rank.inc $(CSRC)/grid_common.inc $(CSRC)/affinity_grid.inc include/glf.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/glf_internal.hpp $(CSRC)/nystroem_grid.inc $(CSRC)/nystroem_rank.inc $(CSRC)/nystroem_band.inc $(CSRC)/grid_common.inc $(CSRC)/affinity_grid.inc include/glf.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/host_util.o: $(CSRC)/host_util.cpp include/glf.h

@@ -93,11 +93,11 @@ int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value)
     glf_tuning &t = ctx->tune;
     if (!std::strcmp(key, "NYS_PATH") || !std::strcmp(key, "DEG_PATH")) {
         const bool nys = key[0] == 'N';
-        if (!unset && !is("grid") && !is("direct") && !(nys && is("rank"))) return GLF_ERR_INVALID;
-        (nys ? t.nys_path : t.deg_path) = unset ? 0 : is("grid") ? 1 : is("rank") ? 3 : 2;
+        if (!unset && !is("grid") && !is("direct") && !(nys && (is("rank") || is("band")))) return GLF_ERR_INVALID;
+        (nys ? t.nys_path : t.deg_path) = unset ? 0 : is("grid") ? 1 : is("rank") ? 3 : is("band") ? 4 : 2;
     } else if (!std::strcmp(key, "MV_PATH")) {
-        if (!unset && !is("grid") && !is("dense") && !is("rank")) return GLF_ERR_INVALID;
-        t.mv_path = unset ? 0 : is("grid") ? 1 : is("rank") ? 3 : 2;
+        if (!unset && !is("grid") && !is("dense") && !is("rank") && !is("band")) return GLF_ERR_INVALID;
+        t.mv_path = unset ? 0 : is("grid") ? 1 : is("rank") ? 3 : is("band") ? 4 : 2;
     } else if (!std::strcmp(key, "ROWPASS")) {
         if (!unset && !is("rt") && !is("v1")) return GLF_ERR_INVALID;
         t.rowpass = is("v1") ? 1 : 0;

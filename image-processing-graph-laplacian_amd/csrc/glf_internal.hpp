@@ -27,9 +27,9 @@ struct glf_pool_block {
 // computes the same sums and is tested against the oracle and against the others. Set with glf_ctx_set_tuning, initialised at
 // context creation from the environment variables GLF_<KEY> (read once, never per call).
 struct glf_tuning {
-    int nys_path = 0;            // NYS_PATH: 0 auto, 1 grid (factored Nystroem, all 256 grey levels), 2 direct (entry by entry), 3 rank (factored, photometric table as a rank-R expansion)
+    int nys_path = 0;            // NYS_PATH: 0 auto, 1 grid (factored Nystroem, all 256 grey levels), 2 direct (entry by entry), 3 rank (factored, photometric table as a rank-R expansion), 4 band (entry by entry, only the samples within the kernel's radius)
     int deg_path = 0;            // DEG_PATH: likewise for the degree
-    int mv_path = 0;             // MV_PATH: 0 auto, 1 grid (L_A applied in factored form), 2 dense (stored L_A), 3 rank (factored, rank-R photometric table)
+    int mv_path = 0;             // MV_PATH: 0 auto, 1 grid (L_A applied in factored form), 2 dense (stored L_A), 3 rank (factored, rank-R photometric table), 4 band (entry by entry within the radius, L_A never stored)
     int rowpass = 0;             // ROWPASS: row pass of the Nystroem passes: 0 / rt = row-tile form, 1 / v1 = one image row per wave
     int rowpass_op = 0;          // ROWPASS_OP: row pass of the L_A sweeps: 0 / v1, 1 / rt
     bool sweep_samples = false;  // SWEEP_COLPASS: rank-form L_A sweeps: false / segments = k_rank_colpass on the samples, true / samples = k_rank_samples

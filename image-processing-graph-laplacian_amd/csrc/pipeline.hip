@@ -567,7 +567,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         ~GridOpGuard() { grid_op_destroy(op); }
     } gop;
     {
-        const bool want = (ctx->tune.mv_path == 1 || ctx->tune.mv_path == 3) ? true : ctx->tune.mv_path == 2 ? false : p >= 16384;
+        const bool want = (ctx->tune.mv_path == 1 || ctx->tune.mv_path == 3 || ctx->tune.mv_path == 4) ? true : ctx->tune.mv_path == 2 ? false : p >= 16384;
         if (want && opt.kernel != GLF_KERNEL_NLM) {
             const int rc = grid_op_create(ctx, tb.samples.p, h_idx, p, width, height, coef, &gop.op);
             if (rc != GLF_OK && rc != GLF_ERR_UNSUPPORTED) return rc;
