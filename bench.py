@@ -435,11 +435,18 @@ def main():
                     "identical_to_hbm_resident_output": bool(torch.equal(h_out, d_out.cpu()))}
 
     # exact_grid_form leg: the same step with the grid-factored contractions carrying all 256 grey levels through HBM
-    exact_leg = None
-    if not args.no_exact_leg and info["nystroem_path"] == 3:
+    exact_leg = rank_leg = None
+    if not args.no_exact_leg and info["nystroem_path"] in (3, 4):
         ctx.set_tuning(NYS_PATH="grid", MV_PATH="grid")
         try:
             exact_leg = run_leg(opt)
+        finally:
+            ctx.set_tuning(NYS_PATH=None, MV_PATH=None)
+    # rank_form leg: the same step with the grid-factored contractions in rank form (round 3's first default)
+    if not args.no_exact_leg and info["nystroem_path"] == 4:
+        ctx.set_tuning(NYS_PATH="rank", MV_PATH="rank")
+        try:
+            rank_leg = run_leg(opt)
         finally:
             ctx.set_tuning(NYS_PATH=None, MV_PATH=None)
     skip_leg = None
@@ -451,7 +458,7 @@ def main():
     # direct_contraction leg: ONE step with the entry-by-entry Nystroem kernel (k_nystroem_f16s: K_B generated in registers,
     # the "true dense contraction" of north_star, SURVEY 8d's W_nys = 2 (N - p) p m) so that it has a driver-timed number
     direct_leg = None
-    if not args.no_direct_leg and info["nystroem_path"] in (1, 3):
+    if not args.no_direct_leg and info["nystroem_path"] in (1, 3, 4):
         ctx.set_tuning(NYS_PATH="direct")
         try:
             ctx.image_processing(d_img, opt, out=d_out)          # warm-up (tables, pool)
@@ -486,12 +493,18 @@ def main():
             ld *= 2
         grid_path = info["nystroem_path"] in (1, 3)
         rank_path = info["nystroem_path"] == 3
+        band_path = info["nystroem_path"] == 4
         R = info.get("rank_terms", 0)
         issued = info["nystroem_mfma_flops"] / (avg_ms * 1e-3) / 1e12
         if info["contraction"] == glf.CONTRACT_F16_SPLIT:
             # every f32-equivalent multiply-add is three f16 MFMA products (hi*hi + hi*lo + lo*hi)
             nys_peak = PEAK_F16_MFMA_TFLOPS
-            if rank_path:
+            if band_path:
+                nys_kernel = ("k_band<%d,2,8,false> (band form: per pixel only the samples within the radius at which 2^15 Er Ec rounds to a "
+                              "zero f16 pair -- 211 px at h_loc = 40 -- are evaluated: per (grid row in the band, block of 16 sample columns) the "
+                              "32 x 16 entries (Er15 Ec) P(|dv|) are generated from LDS tables, split into f16 hi+lo and contracted with the (hi, lo) "
+                              "fragments of Psi, staged by LDS-DMA, on v_mfma_f32_32x32x16_f16; no intermediate reaches HBM)" % (min(ld, 64) // 32))
+            elif rank_path:
                 nys_kernel = ("k_grid_rowpass_rt<RANK> + k_rank_colpass<%d> (grid-factored Nystroem contraction, rank form: the photometric "
                               "table P(|v - w|) as its rank-%d eigen-expansion F F^T (max error <= 2^-30); S[r][b][k] = sum_a Er f_k(v_ab) Psi "
                               "on v_mfma_f32_32x32x16_f16 with both operands split into f16 hi+lo pairs, then per (image row, segment of <= 32 "
@@ -508,7 +521,7 @@ def main():
             nys_peak = PEAK_F32_MFMA_TFLOPS
             nys_kernel = "k_nystroem<%d,%d> (direct Nystroem contraction, v_mfma_f32_32x32x2_f32)" % (ld // 32, 2 if ld <= 128 else 1)
         nystroem = {
-            "kernel": nys_kernel, "path": "grid-factored, rank form (NYS_PATH=rank)" if rank_path else "grid-factored" if grid_path else "direct",
+            "kernel": nys_kernel, "path": "band form (NYS_PATH=band)" if band_path else "grid-factored, rank form (NYS_PATH=rank)" if rank_path else "grid-factored" if grid_path else "direct",
             "rank_terms": R,
             "avg_ms_per_step": round(avg_ms, 3), "launches_per_step": info["nystroem_launches"],
             "algorithmic_flops": flops, "algorithmic_tflops": round(achieved, 1),
@@ -527,7 +540,8 @@ def main():
             prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key, {})
         except (OSError, ValueError):
             pass
-        sweeps = {"path": ("grid-factored, rank form (L_A never stored; S = 0.7 GB per sweep instead of T = 5.6 GB)" if info["matvec_path"] == 3 else
+        sweeps = {"path": ("band form (L_A never stored: k_band<.,1,8,true> on the samples within the radius of each sample; Y = alpha (D X - K_A X) in its epilogue)" if info["matvec_path"] == 4 else
+                           "grid-factored, rank form (L_A never stored; S = 0.7 GB per sweep instead of T = 5.6 GB)" if info["matvec_path"] == 3 else
                            "grid-factored (L_A never stored)" if info["matvec_path"] == 1 else "stored L_A streamed (k_block_matvec_f16s)"),
                   "launches_per_step": mvs["launches"] / args.steps, "avg_ms": round(mv_avg_ms, 4),
                   "ms_per_step": round(mvs["ms"] / args.steps, 3),
@@ -537,7 +551,31 @@ def main():
         # by the 32-row MFMA tiles but never stored or read)
         present = float(np.mean([np.unique(img[r]).size for r in range(info["row0"], info["row1"])])) / 256.0
         cps = info["cp"]
-        if rank_path and cps["launches"] > 0:
+        if band_path and cps["launches"] > 0:
+            # dominant kernel of the band form: the Nystroem launch of k_band (the L_A sweeps run the same kernel on the samples)
+            cp_avg_ms = cps["ms"] / cps["launches"]
+            cp_flops = cps["flops"] / cps["launches"]
+            cp_tflops = cp_flops / (cp_avg_ms * 1e-3) / 1e12
+            cp_peak = PEAK_F16_MFMA_TFLOPS / 3.0
+            ev_flops = 2.0 * info["nystroem_evaluated"] * min(ld, 64)
+            roofline = {
+                "kernel": "k_band<%d,2,8,false> (Phi[px][n] = sum over the samples within the radius of (Er15 Ec P)[px][s] Psi[s][n]: entries "
+                          "generated on the vector pipe from LDS tables and split into f16 hi+lo, v_mfma_f32_32x32x16_f16 with the Psi "
+                          "fragments staged by LDS-DMA, f32 accumulate; 8 waves = 8 image rows x 64 columns per workgroup)" % (min(ld, 64) // 32),
+                "bound": "mfma", "achieved": round(cp_tflops, 1), "peak": round(cp_peak, 1), "unit": "TFLOP/s",
+                "frac": round(cp_tflops / cp_peak, 4), "traffic": prof.get("band_bytes_per_launch"),
+                "traffic_source": prof.get("band_source", "none: no committed --pmc pass for this configuration"),
+                "avg_launch_ms": round(cp_avg_ms, 4), "launches_per_step": cps["launches"] / args.steps,
+                "flops_per_launch": cp_flops, "ms_per_step": round(cps["ms"] / args.steps, 3),
+                "evaluated_tflops": round(ev_flops / (cp_avg_ms * 1e-3) / 1e12, 1),
+                "evaluated_frac_of_peak": round(ev_flops / (cp_avg_ms * 1e-3) / 1e12 / cp_peak, 4),
+                "peak_basis": "f16 dense MFMA peak 2500 TFLOP/s / 3 products per split-precision multiply-add (nominal)",
+                "note": "achieved = algorithmic flops of the launch -- 2 m x the (pixel, sample) pairs whose distance is inside the radius "
+                        "(the circle), one product per multiply-add -- / mean HIP-event duration of the launch. The entries evaluated are "
+                        "~1.8x that (whole blocks of 16 sample columns x 64-pixel tiles cover the circle: evaluated_*). traffic = FETCH_SIZE x 2 "
+                        "+ WRITE_SIZE of the launch from the committed rocprofv3 --pmc passes named in traffic_source: the Psi fragments "
+                        "(24 MB, L2-resident) + the Phi write"}
+        elif rank_path and cps["launches"] > 0:
             # dominant kernel of the rank form: the fused T' + column pass of the Nystroem stage (the L_A sweeps run the same kernel
             # over the nr grid rows)
             cp_avg_ms = cps["ms"] / cps["launches"]
@@ -613,6 +651,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d synthetic noisy image, %.1f%% samples (p=%d), m=%d eigenpairs, eps=%g, "
                                    "no exact-zero skipping (every kernel entry enters the sums: %s)" % (size, size, args.sample_frac * 100, p, m, args.epsilon,
+                                   "band form: the samples beyond the radius contribute exact zeros in this arithmetic" if band_path else
                                    "grid-factored forms, rank-%d photometric expansion" % R if rank_path else
                                    "grid-factored forms" if info["nystroem_path"] == 1 else "entry-by-entry kernels"),
                        "N": N, "p": p, "m": m, "epsilon": args.epsilon, "outer_its": info["outer_its"],
@@ -639,9 +678,16 @@ def main():
             e_sec, e_info, e_avg_ms, e_stage = exact_leg
             line["exact_grid_form"] = {
                 "what": "same workload with GLF_NYS_PATH = GLF_MV_PATH = grid: the grid-factored contractions carrying all 256 grey levels "
-                        "(T = 78 GB per image through HBM); the rank form replaces the photometric table by its rank-%d expansion" % R,
+                        "(T = 78 GB per image through HBM)",
                 "value": round(N / e_sec * 1e-6, 4), "unit": "Mpixel/s", "ms_per_step": round(e_sec * 1e3, 3), "stage_ms_rank0": e_stage,
                 "outer_its": e_info["outer_its"], "inner_its_total": e_info["inner_its_total"]}
+        if rank_leg is not None:
+            r_sec, r_info, r_avg_ms, r_stage = rank_leg
+            line["rank_form"] = {
+                "what": "same workload with GLF_NYS_PATH = GLF_MV_PATH = rank: the grid-factored contractions with the photometric table as "
+                        "its rank-%d expansion (S = 10 GB per image through HBM instead of T = 78 GB; T' formed in LDS)" % r_info.get("rank_terms", 0),
+                "value": round(N / r_sec * 1e-6, 4), "unit": "Mpixel/s", "ms_per_step": round(r_sec * 1e3, 3), "stage_ms_rank0": r_stage,
+                "outer_its": r_info["outer_its"], "inner_its_total": r_info["inner_its_total"]}
         if skip_leg is not None:
             s_sec, s_info, s_avg_ms, s_stage = skip_leg
             dense_evals = float(p) * npix_local

@@ -75,19 +75,20 @@ def _residual_fp64(torch, LA, p, X):
     return float(torch.linalg.norm(R)), torch.linalg.eigvalsh(0.5 * (G + G.T)).cpu().numpy()
 
 
-@pytest.mark.parametrize("size,form,gain", [(1024, "rank", 3.0), (2048, "rank", 3.0), (2048, "grid", 3.0), (2048, "rank", 2000.0),
-                                            (4096, "rank", 3.0), (4096, "grid", 3.0)])
+@pytest.mark.parametrize("size,form,gain", [(1024, "band", 3.0), (2048, "band", 3.0), (2048, "rank", 3.0), (2048, "grid", 3.0),
+                                            (2048, "band", 2000.0), (4096, "band", 3.0), (4096, "rank", 3.0), (4096, "grid", 3.0)])
 def test_headline_config_sampled_parity(ctx, size, form, gain):
-    """form: "rank" = the default kernels (grid-factored contractions with the photometric table as a rank-R expansion, T'
-    formed in LDS: what bench.py's headline times), "grid" = the same contractions carrying all 256 grey levels through
-    HBM (GLF_NYS_PATH / GLF_MV_PATH = grid: bench.py's second leg). 1024: BASELINE cfg5's tile (m = 64, whole path). gain:
+    """form: "band" = the default kernels (k_band: the kernel entries of the samples within the radius of each target generated
+    and contracted directly: what bench.py's headline times), "rank" / "grid" = the grid-factored contractions, which carry every
+    sample (rank: the photometric table as a rank-R expansion, T' formed in LDS; grid: all 256 grey levels through HBM;
+    GLF_NYS_PATH / GLF_MV_PATH: bench.py's other legs). 1024: BASELINE cfg5's tile (m = 64, whole path). gain:
     hpc/display.c:73 has 3.0, with which the filter moves a pixel by ~1e-3 grey levels at these sizes -- the 8-bit output
     is y or y - 1 and its comparison nearly vacuous; the gain = 2000 case moves pixels by several grey levels, so that the
     u8 / PSNR comparison with the oracle can fail."""
     torch = ctx.torch
     ctx.reset_tuning()
-    if form == "grid":
-        ctx.set_tuning(NYS_PATH="grid", MV_PATH="grid")
+    if form != "band":
+        ctx.set_tuning(NYS_PATH=form, MV_PATH=form)
     img = glf.synth_image(size, size, seed=0)
     assert zlib.crc32(img.tobytes()) == SYNTH_CRC32[size]
     N, m, eps = size * size, 64, 0.1
@@ -99,12 +100,12 @@ def test_headline_config_sampled_parity(ctx, size, form, gain):
     opt = glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps)
     opt.gain = gain
     if size == 1024:
-        ctx.set_tuning(MV_PATH="rank")        # (auto keeps a stored L_A below 16384 samples; the tile goes through the rank form here)
+        ctx.set_tuning(MV_PATH="band")        # (auto keeps a stored L_A below 16384 samples; the tile goes through the band form here)
     out, zf, info = ctx.image_processing(d_img, opt, want_float=True, capture=True)
     ctx.reset_tuning()
     cap = info["capture"]
     # the kernel families bench.py times
-    want_path = 3 if form == "rank" else 1
+    want_path = {"band": 4, "rank": 3, "grid": 1}[form]
     assert info["nystroem_path"] == want_path and info["matvec_path"] == want_path and info["contraction"] == glf.CONTRACT_F16_SPLIT
     assert (info["p"], info["m"], cap["ld"]) == (p, m, 64)
     assert torch.isfinite(zf).all() and info["residual"] <= eps
@@ -168,7 +169,7 @@ def test_headline_config_sampled_parity(ctx, size, form, gain):
     if gain > 100.0:     # the filter must be visible in this case: the reference output differs from the input by >= 1 grey level RMS
         assert res["rms_correction_grey_levels"] >= 1.0 and res["psnr_ref_vs_input_db"] < 48.0
     report["eigvals_min_max"] = [float(lam.min()), float(lam.max())]
-    _record("large_parity_%d%s%s.json" % (size, "" if form == "rank" else "_grid", "" if gain == 3.0 else "_gain%g" % gain), report)
+    _record("large_parity_%d%s%s.json" % (size, "" if form == "band" else "_" + form, "" if gain == 3.0 else "_gain%g" % gain), report)
     print(json.dumps(report, default=float))
     assert res["phi_max_abs_err_over_max"] <= PHI_TOL
     assert res["rel_l2_correction"] <= CORR_TOL                       # the correction term z - y itself
@@ -189,7 +190,7 @@ def test_headline_config_sampled_parity(ctx, size, form, gain):
     out_all = torch.clamp(torch.floor(z_all), 0.0, 255.0).to(torch.uint8)        # trunc(z) for z >= 0, 0 below (Q4); clamp at 255 (hpc/display.c:75-78)
     mism = float((out_all.reshape(size, size) != out).double().mean())
     report["u8_mismatch_frac_all_pixels"] = mism
-    _record("large_parity_%d%s%s.json" % (size, "" if form == "rank" else "_grid", "" if gain == 3.0 else "_gain%g" % gain), report)
+    _record("large_parity_%d%s%s.json" % (size, "" if form == "band" else "_" + form, "" if gain == 3.0 else "_gain%g" % gain), report)
     assert mism <= 1e-4, mism               # only where the f32 / f64 corrections straddle an integer
 
 
@@ -203,8 +204,8 @@ HDR_KERNELS = [
 
 @pytest.mark.parametrize("size", [1024, 2048])
 def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
-    """Phi and z - y from (a) the default contraction (grid-factored, rank form), (a') the grid-factored form carrying all 256
-    grey levels, (b) the entry-by-entry split-f16 kernel and (c) the exact-f32-operand MFMA kernel, each against the fp64 oracle on sampled rows; same Phi_A / eigenvalues for all
+    """Phi and z - y from (a) the default contraction (band form), (a') the grid-factored forms (rank form; all 256
+    grey levels), (b) the entry-by-entry split-f16 kernel and (c) the exact-f32-operand MFMA kernel, each against the fp64 oracle on sampled rows; same Phi_A / eigenvalues for all
     three (one eigen-solve)."""
     torch = ctx.torch
     img = glf.synth_image(size, size, seed=0)
@@ -229,10 +230,10 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
         phi_A = ctx.mat_to_numpy(vecs)
         Pi_inv = ctx.InverseDiagMat(vals)
         got = {}
-        for mode in ("rank_f16s", "grid_f16s", "direct_f16s", "direct_f32"):
+        for mode in ("band_f16s", "rank_f16s", "grid_f16s", "direct_f16s", "direct_f32"):
             ctx.set_contraction(glf.CONTRACT_F32_MFMA if mode == "direct_f32" else glf.CONTRACT_F16_SPLIT)
             # (rank: h_val = 5 needs more than 64 terms for 2^-30 -- that kernel falls back to the exact grid form, by design)
-            ctx.set_tuning(NYS_PATH={"rank_f16s": "rank", "grid_f16s": "grid"}.get(mode, "direct"))
+            ctx.set_tuning(NYS_PATH={"band_f16s": "band", "rank_f16s": "rank", "grid_f16s": "grid"}.get(mode, "direct"))
             phi_sf = ctx.Nystroem(L_B, vecs, Pi_inv)
             phi = ctx.Permutation(phi_sf, idx)
             ctx.destroy(phi_sf)
@@ -259,7 +260,7 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
         # the split-f16 results against the exact-f32-operand kernel directly (same rows): the 22-bit operands cost less
         # than the fp32 accumulation already does
         ref32 = got["direct_f32"][0].double()
-        for mode in ("rank_f16s", "grid_f16s", "direct_f16s"):
+        for mode in ("band_f16s", "rank_f16s", "grid_f16s", "direct_f16s"):
             d = float((got[mode][0].double() - ref32).abs().max() / ref32.abs().max())
             report[key][mode + "_vs_f32_max_abs_over_max"] = d
             assert d <= PHI_TOL, (key, mode, d)
@@ -269,7 +270,7 @@ def test_contraction_arithmetic_bounds(ctx, size, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mv", ["rank", "grid"])
+@pytest.mark.parametrize("mv", ["band", "rank", "grid"])
 @pytest.mark.parametrize("size,m", [(1024, 64), (1024, 100)])
 def test_narrow_sweeps_return_the_same_numbers(size, m, mv):
     """Block PCG applies the operator to the still-iterating columns only once few are left (packed into a block of 32

@@ -40,14 +40,14 @@ def _check(img, opt, n, backend, devices):
 
 
 def _env_paths(monkeypatch, paths):
-    """direct: entry-by-entry kernels, stored L_A; grid / rank: the grid-factored forms (rank: the default at benchmark sizes)"""
+    """direct: entry-by-entry kernels, stored L_A; grid / rank: the grid-factored forms; band: entry by entry within the radius (the default at benchmark sizes)"""
     monkeypatch.setenv("GLF_NYS_PATH", paths)
     monkeypatch.setenv("GLF_DEG_PATH", "direct" if paths == "direct" else "grid")
-    monkeypatch.setenv("GLF_MV_PATH", {"direct": "dense", "grid": "grid", "rank": "rank"}[paths])
+    monkeypatch.setenv("GLF_MV_PATH", {"direct": "dense", "grid": "grid", "rank": "rank", "band": "band"}[paths])
 
 
 @pytest.mark.parametrize("n", [1, 2, 3])
-@pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
+@pytest.mark.parametrize("paths", ["direct", "grid", "rank", "band"])
 def test_loopback_ranks_on_one_device_match_single_context(n, paths, monkeypatch):
     _env_paths(monkeypatch, paths)
     img = glf.synth_image(96, 80, seed=4)
@@ -60,18 +60,18 @@ def test_loopback_more_ranks_than_grid_rows_and_odd_shards(monkeypatch):
     eigen-solve; image row shards of 7 or 8 rows) in both kernel families."""
     img = glf.synth_image(53, 37, seed=3)
     opt = glf.default_options(num_samples=20, num_eigvals=5, epsilon=0.1)
-    for paths in ("direct", "grid", "rank"):
+    for paths in ("direct", "grid", "rank", "band"):
         _env_paths(monkeypatch, paths)
         _check(img, opt, 5, glf.MULTI_LOOPBACK, [0] * 5)
 
 
 def test_loopback_two_ranks_1024_default_paths():
-    """1024 x 1024, 0.5 %, m = 64 on 2 ranks with the kernels chosen by default at that size (grid-factored degree and
-    Nystroem passes; stored L_A column blocks for the p = 5329 eigen-solve)."""
+    """1024 x 1024, 0.5 %, m = 64 on 2 ranks with the kernels chosen by default at that size (grid-factored degree pass, band-form
+    Nystroem pass; stored L_A column blocks for the p = 5329 eigen-solve)."""
     img = glf.synth_image(1024, 1024, seed=5)
     opt = glf.default_options(num_samples=int(1024 * 1024 * 0.005), num_eigvals=64, epsilon=0.1)
     infos = _check(img, opt, 2, glf.MULTI_LOOPBACK, [0, 0])
-    assert infos[0]["nystroem_path"] == 3   # the rank form of the grid-factored contraction
+    assert infos[0]["nystroem_path"] == 4   # the band form (the samples within the radius of each pixel only)
 
 
 def test_rccl_one_rank_world():

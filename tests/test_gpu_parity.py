@@ -58,11 +58,15 @@ def _default_kernel_selection(request):
         request.getfixturevalue("ctx").reset_tuning()
 
 
+PATH_ID = {"grid": 1, "rank": 3, "band": 4}   # glf_stats.nystroem_path / matvec_path
+
+
 def _set_paths(ctx, paths):
-    """Kernel family of the three K_B / K_A stages: "direct" (entry by entry; stored L_A), "grid" (grid-factored, all 256 grey
-    levels) or "rank" (grid-factored with the photometric table as a rank-R expansion: the default at benchmark sizes)."""
+    """Kernel family of the three K_B / K_A stages: "direct" (entry by entry over ALL samples; stored L_A), "grid" (grid-factored, all
+    256 grey levels), "rank" (grid-factored with the photometric table as a rank-R expansion) or "band" (entry by entry over the
+    samples within the kernel's radius only: the default at benchmark sizes)."""
     ctx.set_tuning(NYS_PATH=paths, DEG_PATH="direct" if paths == "direct" else "grid",
-                   MV_PATH={"direct": "dense", "grid": "grid", "rank": "rank"}[paths])
+                   MV_PATH={"direct": "dense", "grid": "grid", "rank": "rank", "band": "band"}[paths])
 
 
 def _lapack_pairs(LA, m):
@@ -254,7 +258,7 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
     Pi_inv = ctx.InverseDiagMat(Pi)
     got = {}
     for mode, tune in (("grid", {"NYS_PATH": "grid"}), ("grid_v1", {"NYS_PATH": "grid", "ROWPASS": "v1"}),
-                       ("rank", {"NYS_PATH": "rank"}),
+                       ("rank", {"NYS_PATH": "rank"}), ("band", {"NYS_PATH": "band"}),
                        ("lut", {"NYS_PATH": "direct"}), ("exp", {"NYS_PATH": "direct", "NYS_NO_LUT": "1"})):
         ctx.set_tuning(NYS_PATH=None, NYS_NO_LUT=None, ROWPASS=None)
         ctx.set_tuning(**tune)
@@ -269,6 +273,8 @@ def test_nystroem_paths_agree(ctx, w, h, ns, m, monkeypatch):
     np.testing.assert_allclose(got["grid"], got["exp"], rtol=0, atol=2e-5 * scale)
     # rank form: the photometric table as its rank-R eigen-expansion (max |F F^T - P| <= 2^-30), T' formed in LDS
     np.testing.assert_allclose(got["rank"], got["exp"], rtol=0, atol=2e-5 * scale)
+    # band form: the same entries as the direct kernel generates, those beyond the radius (exact zeros in this arithmetic) left out
+    np.testing.assert_allclose(got["band"], got["lut"], rtol=0, atol=2e-6 * scale)
     # the two row-pass kernels (row-tile form: Er as the A operand; v1: one image row per wave) split different operands
     np.testing.assert_allclose(got["grid"], got["grid_v1"], rtol=0, atol=2e-5 * scale)
     ctx.destroy(L_A, phi_A, Pi, Pi_inv, K_B)
@@ -441,6 +447,21 @@ def test_end_to_end_with_rank_forms_forced(ctx, golden, png, name, ns, m, eps, s
                                          want_float=True)
     if info["contraction"] == glf.CONTRACT_F16_SPLIT:
         assert info["nystroem_path"] == 3 and info["matvec_path"] == 3
+    _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info)
+
+
+@pytest.mark.parametrize("name,ns,m,eps", [("ragged", 20, 5, 0.1), ("cat50", 50, 53, 0.1), ("test", 100, 16, 0.1), ("test", 400, 70, 0.1)])
+def test_end_to_end_with_band_form_forced(ctx, golden, png, name, ns, m, eps):
+    """The band form (k_band: the kernel entries of the samples within the radius of each target generated and contracted
+    directly; the default once the radius is small against the image) forced on the small reference images -- whose every
+    sample lies within the radius, so the band is the whole grid -- for the Nystroem extension and the L_A sweeps, against
+    the fp64 oracle."""
+    ctx.set_tuning(NYS_PATH="band", DEG_PATH="grid", MV_PATH="band")
+    img, _ = _images(golden, png)[name]
+    out, zf, info = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
+                                         want_float=True)
+    if info["contraction"] == glf.CONTRACT_F16_SPLIT:
+        assert info["nystroem_path"] == 4 and info["matvec_path"] == 4
     _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info)
 
 
@@ -621,7 +642,7 @@ def test_entire_computation_no_approx(ctx, png, shape):
     assert 0 < alpha < 1
 
 
-@pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
+@pytest.mark.parametrize("paths", ["direct", "grid", "rank", "band"])
 @pytest.mark.parametrize("w,h,ns,m", [(16, 12, 6, 2), (24, 31, 9, 3), (200, 160, 500, 128), (256, 256, 655, 256)])
 def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     """Tiny images (p < one 64-sample chunk) and the widest supported blocks (ld = 128, 256: the MB = 4 / 8
@@ -634,7 +655,7 @@ def test_extreme_shapes_end_to_end(ctx, w, h, ns, m, paths, monkeypatch):
     out, zf, info = ctx.image_processing(ctx.to_device(img), opt, want_float=True)
     out, zf = out.cpu().numpy(), zf.cpu().numpy()
     if paths != "direct" and info["contraction"] == glf.CONTRACT_F16_SPLIT and info["p"] >= 4:
-        assert info["nystroem_path"] == (1 if paths == "grid" else 3)
+        assert info["nystroem_path"] == PATH_ID[paths]
     _assert_end_to_end(img, ns, m, eps, out, zf, info)
 
 
@@ -729,7 +750,7 @@ def test_nlm_kernel_refuses_images_below_3x3(ctx):
         assert e.value.status == glf.ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("paths", ["direct", "grid", "rank"])
+@pytest.mark.parametrize("paths", ["direct", "grid", "rank", "band"])
 @pytest.mark.parametrize("ns,m", [(600, 0), (600, 300), (300, 257)])
 def test_more_than_256_eigenpairs_end_to_end(ctx, ns, m, paths, monkeypatch):
     """The reference's default is m = p - 1 eigenpairs (hpc/image_processing.c:96-108; num_eigvals = 0 here): beyond 256 the
