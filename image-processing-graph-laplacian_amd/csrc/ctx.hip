@@ -155,6 +155,7 @@ int glf_ctx_destroy(glf_ctx *ctx)
     glf::native_comm_release(ctx);
     if (ctx->mv_scratch) (void)hipFree(ctx->mv_scratch);
     if (ctx->x0_block) (void)hipFree(ctx->x0_block);
+    glf::band_cache_free(ctx);
     if (ctx->rank_ftab) (void)hipFree(ctx->rank_ftab);
     if (ctx->rank_ff) (void)hipFree(ctx->rank_ff);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

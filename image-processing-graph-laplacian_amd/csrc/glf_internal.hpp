@@ -79,6 +79,9 @@ struct glf_ctx {
     // after a stream synchronise; no D2H copy launches, and no hipHostMalloc per image): see glf::ctx_pinned()
     void *pinned = nullptr;
     // rank form of the grid-factored contractions (nystroem_rank.inc): the factor F of the photometric table for one scale
+    // band form (nystroem_band.inc): the geometry tables of the last (sample grid, kernel, image size), pixels / samples as targets
+    // -- they depend on neither the image nor the operand, so consecutive images of one size reuse them (a plan)
+    void *band_cache[2] = {nullptr, nullptr};
     bool rank_valid = false;
     float rank_s_val = 0.f;
     int rank_R = 0;             // terms of the expansion (0: the table is not low-rank enough, the exact form runs)
@@ -325,6 +328,7 @@ int grid_op_create(glf_ctx *ctx, const float4 *d_samples, const unsigned *h_idx,
                    KernelCoef coef, GridOp **out); // GLF_ERR_UNSUPPORTED: not a tensor grid (or not the split-f16 mode)
 void grid_op_destroy(GridOp *op);
 unsigned grid_op_rows_per_rank(const GridOp *op, int size); // all-gather block: whole grid rows
+void band_cache_free(glf_ctx *ctx);
 int grid_op_path(const GridOp *op);                          // glf_stats.matvec_path: 1 exact grid form, 3 rank form
 int grid_op_apply(glf_ctx *ctx, GridOp *op, const float *X, float *Y, unsigned ld, double alpha, const double *d_degree,
                   unsigned row0, unsigned row1, int window);
