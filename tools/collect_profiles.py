@@ -75,7 +75,8 @@ entry = traffic.setdefault("4096x4096_m64_f16s_gpus1", {})
 # (k_rank_colpassILi2ELb0: the Nystroem launch of the rank form -- Lb1 is the L_A sweeps' instantiation of the same kernel;
 #  k_grid_rowpass_rt..ELb0ELb1: the rank-form row pass of the Nystroem stage)
 for name, key in (("k_block_matvec_f16s", "matvec"), ("k_grid_rowpass", "grid_rowpass"), ("k_grid_colpass", "grid_colpass"),
-                  ("k_rank_colpassILi2ELb0", "rank_colpass"), ("k_rank_colpassILi2ELb1", "rank_colpass_op")):
+                  ("k_rank_colpassILi2ELb0", "rank_colpass"), ("k_rank_colpassILi2ELb1", "rank_colpass_op"),
+                  ("k_band<2, 2, 8, false>", "band"), ("k_band<2, 1, 8, true>", "band_op")):
     ks = [k for k in summary if name in k and "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]]
     if not ks:
         continue
