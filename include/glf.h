@@ -64,7 +64,8 @@ int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *nu
                         size_t *total_mem_bytes);
 /* Kernel selection. Several stages have more than one implementation of the same sums (grid-factored vs entry by entry, two
  * row-pass shapes, ...); the default picks by problem size. key / value (value NULL, "" or "auto" = default):
- *   NYS_PATH, DEG_PATH  grid | direct        MV_PATH   grid | dense        ROWPASS, ROWPASS_OP  rt | v1
+ *   NYS_PATH  band | rank | grid | direct     DEG_PATH  grid | direct     MV_PATH  band | rank | grid | dense
+ *   ROWPASS, ROWPASS_OP  rt | v1     COLPASS  ws | v1     SWEEP_COLPASS  segments | samples
  *   NYS_NO_LUT, NO_ECR, NO_NARROW, VERBOSE  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
  * At context creation each key is initialised from the environment variable GLF_<KEY> (read once; nothing reads the
  * environment per call). No reference counterpart (PETSc's -ksp_type / -pc_type options database is the nearest thing). */
@@ -348,8 +349,12 @@ typedef struct glf_stats {
     /* f16 MFMA flops issued by the Nystroem contraction (3 products per split multiply-add) */
     double nystroem_mfma_flops;
     int32_t nystroem_path;  /* 0 direct kernel (K_B generated entry by entry), 1 grid-factored (all 256 grey levels),
-                               3 grid-factored in rank form (photometric table as a rank-R expansion) */
-    int32_t matvec_path;    /* 0 stored L_A streamed per sweep, 1 L_A applied in grid-factored form (never stored), 3 the same in rank form */
+                               3 grid-factored in rank form (photometric table as a rank-R expansion),
+                               4 band form (entry by entry over the samples within the kernel's radius; then nystroem_evaluated
+                               counts the entries the kernel evaluated and nystroem_colpass_* describe its launches, with
+                               nystroem_colpass_flops = 2 ld x the (pixel, sample) pairs inside the radius) */
+    int32_t matvec_path;    /* 0 stored L_A streamed per sweep, 1 L_A applied in grid-factored form (never stored), 3 the same in rank form,
+                               4 L_A applied in band form (never stored) */
     /* grid-factored Nystroem: the row-pass kernel (k_grid_rowpass) alone -- launches, summed device ms (HIP events around
      * each launch) and its algorithmic flops 2 rows 256 nc nr ld (one product per multiply-add) */
     int32_t nystroem_rowpass_launches;
