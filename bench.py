@@ -665,6 +665,7 @@ def main():
                                    (n_gpus, n_gpus, "none" if n_gpus == 1 and not args.force_comm else
                                     ("RCCL issued by the library" if args.comm == "rccl" else "torch.distributed callbacks"))},
             "stage_ms_rank0": stage_ms,
+            "filter_fused": bool(info.get("filter_fused", 0)),
             "roofline": roofline,
             "eigen_sweeps": sweeps,
             "nystroem": nystroem,

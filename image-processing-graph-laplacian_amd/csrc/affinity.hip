@@ -384,15 +384,19 @@ int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int heig
 // direct sweep (windowed when exact zeros may be skipped). *evaluated = kernel entries represented.
 int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
                      unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated,
-                     const uint32_t *d_idx)
+                     const uint32_t *d_idx, double *d_ysum, bool *have_ysum)
 {
+    if (have_ysum) *have_ysum = false;
     if (coef.kernel == GLF_KERNEL_NLM) { // patch distances: no factored form, its own sweep (nlm.hip)
         if (!d_idx) return set_error(ctx, GLF_ERR_INVALID, "NLM degree needs the device sample indices");
         if (evaluated) *evaluated = (double)p * (double)(row1 - row0) * (double)width;
         return nlm_degree_rows(ctx, d_img, width, height, row0, row1, d_idx, p, coef, d_degree);
     }
-    const int rc = degree_rows_grid(ctx, d_img, width, height, row0, row1, d_samples, p, h_idx, coef, d_degree, window, evaluated);
-    if (rc != GLF_ERR_UNSUPPORTED) return rc;
+    const int rc = degree_rows_grid(ctx, d_img, width, height, row0, row1, d_samples, p, h_idx, coef, d_degree, window, evaluated, d_ysum);
+    if (rc != GLF_ERR_UNSUPPORTED) {
+        if (have_ysum) *have_ysum = rc == GLF_OK && d_ysum != nullptr; // (only the grid-factored degree has the value-weighted sums)
+        return rc;
+    }
     if (window && coef.s_loc > 0.f)
         return degree_rows_windowed(ctx, d_img, width, height, row0, row1, d_samples, p, h_idx, coef, d_degree, evaluated);
     if (evaluated) *evaluated = (double)p * (double)(row1 - row0) * (double)width;

@@ -73,6 +73,49 @@ int phi_t_y(glf_ctx *ctx, const float *d_phi, const uint8_t *d_img, int64_t pix0
     return GLF_OK;
 }
 
+// ---- c = Phi^T y without Phi (band form with the filter in the Nystroem kernel's epilogue) ---------------------------------
+// Phi's rows are Phi_A at the sample pixels and sum_s K(px, s) Psi[s] elsewhere, so
+//   c[n] = sum_s Phi_A[s][n] y_s + sum_s Psi[s][n] u_s,   u_s = sum over the NON-sample pixels of K(px, s) y[px]
+// and u = (the degree stage's value-weighted sums over all pixels) - K_A y_A. f64 throughout; 128 samples per workgroup.
+__global__ __launch_bounds__(256) void k_c_from_ysum(const float *__restrict__ psi, const float *__restrict__ phiA,
+                                                      const double *__restrict__ ysum, const float *__restrict__ t, unsigned t_ld,
+                                                      const float4 *__restrict__ samples, unsigned p, unsigned ld,
+                                                      double *__restrict__ partial)
+{
+    __shared__ double sh[256];
+    const int col = threadIdx.x % ld, rl = threadIdx.x / ld, nrl = 256 / ld;
+    double acc = 0.0;
+    const unsigned base = blockIdx.x * 128u;
+    for (unsigned r = rl; r < 128u; r += nrl) {
+        const unsigned s = base + r;
+        if (s >= p) break;
+        const double u = ysum[s] - (double)t[(size_t)s * t_ld];
+        acc = fma((double)psi[(size_t)s * ld + col], u, acc);
+        acc = fma((double)phiA[(size_t)s * ld + col], (double)samples[s].z, acc);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < ld) {
+        double tot = 0.0;
+        for (int r = 0; r < nrl; ++r) tot += sh[r * ld + col];
+        partial[(size_t)blockIdx.x * ld + col] = tot;
+    }
+}
+
+int c_from_ysum(glf_ctx *ctx, const float *d_psi, const float *d_phiA, const double *d_ysum, const float *d_t, unsigned t_ld,
+                const float4 *d_samples, unsigned p, unsigned ld, double *d_c)
+{
+    if (!valid_ld(ld)) return set_error(ctx, GLF_ERR_INVALID, "c_from_ysum: ld=%u", ld);
+    const int nblk = (int)ceil_div(p, 128u);
+    DevBuf<double> part;
+    GLF_TRY(part.alloc(ctx, (size_t)nblk * ld));
+    hipLaunchKernelGGL(k_c_from_ysum, dim3(nblk), dim3(256), 0, ctx->stream, d_psi, d_phiA, d_ysum, d_t, t_ld, d_samples, p, ld, part.p);
+    hipLaunchKernelGGL(k_cols_sum, dim3(ld), dim3(256), 0, ctx->stream, part.p, nblk, ld, d_c);
+    GLF_LAUNCH_CHECK(ctx);
+    GLF_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (part goes out of scope)
+    return GLF_OK;
+}
+
 // partial[blk][i][j] = sum over the pixels of block blk of Phi[px][i] Phi[px][j] (blocks stride the range): the Gram matrix of
 // the extended eigenvectors, which are not orthonormal -- what sits between the factors of the PoC's sharpening filter
 // (python/image_processing.py:231-235). f32 products, f64 across chains of 32.
@@ -159,6 +202,45 @@ __global__ __launch_bounds__(256) void k_apply_filter(const uint8_t *__restrict_
             out[px] = filter_output(y, c);
         }
     }
+}
+
+// the same for n sample pixels, each from its row of Phi_A: px = idx[i] (k_apply_filter's arithmetic)
+template <int LD>
+__global__ __launch_bounds__(256) void k_filter_sample_rows(const uint8_t *__restrict__ img, const float *__restrict__ phiA, unsigned n,
+                                                             const uint32_t *__restrict__ idx, const float *__restrict__ w, float gain,
+                                                             float ysub, uint8_t *__restrict__ out, float *__restrict__ zf,
+                                                             float *__restrict__ corr, int64_t pix0)
+{
+    constexpr int LPP = LD / 4, PPB = 256 / LPP;
+    const int q = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const float4 wq = reinterpret_cast<const float4 *>(w)[q];
+    const unsigned i = blockIdx.x * PPB + pl;
+    const bool live = i < n;
+    const float4 f = live ? reinterpret_cast<const float4 *>(phiA + (size_t)i * LD)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = f.x * wq.x + f.y * wq.y + f.z * wq.z + f.w * wq.w;
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (q == 0 && live) {
+        const int64_t px = (int64_t)idx[i];
+        const int y = (int)img[px];
+        const float c = gain * s - ysub * (float)y;
+        if (zf) zf[px] = (float)y + c;
+        if (corr) corr[px - pix0] = c;
+        out[px] = filter_output(y, c);
+    }
+}
+
+int filter_sample_rows(glf_ctx *ctx, const float *d_phiA, unsigned n, unsigned ld, const uint32_t *d_idx, const uint8_t *d_img,
+                       const float *d_w, float gain, float ysub, uint8_t *d_out, float *d_zf, float *d_corr, int64_t pix0)
+{
+    if (n == 0) return GLF_OK;
+    if (ld != 32 && ld != 64) return set_error(ctx, GLF_ERR_INVALID, "filter_sample_rows: ld=%u", ld);
+    const unsigned ppb = 256 / (ld / 4);
+    const dim3 grid((unsigned)ceil_div(n, ppb)), block(256);
+    if (ld == 32) hipLaunchKernelGGL(k_filter_sample_rows<32>, grid, block, 0, ctx->stream, d_img, d_phiA, n, d_idx, d_w, gain, ysub, d_out, d_zf, d_corr, pix0);
+    else hipLaunchKernelGGL(k_filter_sample_rows<64>, grid, block, 0, ctx->stream, d_img, d_phiA, n, d_idx, d_w, gain, ysub, d_out, d_zf, d_corr, pix0);
+    GLF_LAUNCH_CHECK(ctx);
+    return GLF_OK;
 }
 
 int apply_filter(glf_ctx *ctx, const uint8_t *d_img, const float *d_phi, int64_t pix0, int64_t pix1, unsigned /*m*/,

@@ -38,6 +38,7 @@ struct glf_tuning {
     bool no_ecr = false;         // NO_ECR: column pass reads the per-column Ec fragment table instead of the compact one
     bool gs_seq = false;         // GS=seq: Gram-Schmidt as the column-by-column sweep instead of the Gram-matrix form
     bool residual_sweep = false; // RESIDUAL=sweep: residual from an explicit L_A sweep instead of the PCG state
+    bool no_fused_filter = false; // NO_FUSED_FILTER: band form writes Phi and the filter runs as its own stage (k_apply_filter)
     bool no_narrow = false;      // NO_NARROW: block PCG applies the operator to all columns of the block even when few still iterate
     bool verbose = false;        // VERBOSE: log every outer iteration on stderr (the reference does, hpc/inverse_power_it.c:164-181)
 };
@@ -281,7 +282,7 @@ int mv_collect(glf_ctx *ctx);
 int start_block_cached(glf_ctx *ctx, unsigned p, unsigned m, unsigned ld, unsigned long long seed, const float **d_block);
 int degree_rows_auto(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1, const float4 *d_samples,
                      unsigned p, const unsigned *h_idx, KernelCoef coef, double *d_degree, int window, double *evaluated,
-                     const uint32_t *d_idx = nullptr);
+                     const uint32_t *d_idx = nullptr, double *d_ysum = nullptr, bool *have_ysum = nullptr);
 int degree_rows_windowed(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int row0, int row1,
                          const float4 *d_samples, unsigned p, const unsigned *h_idx, KernelCoef coef,
                          double *d_degree, double *evaluated);
@@ -329,6 +330,27 @@ int grid_op_create(glf_ctx *ctx, const float4 *d_samples, const unsigned *h_idx,
 void grid_op_destroy(GridOp *op);
 unsigned grid_op_rows_per_rank(const GridOp *op, int size); // all-gather block: whole grid rows
 void band_cache_free(glf_ctx *ctx);
+// Filter applied in the epilogue of the band-form Nystroem kernel: z = y + gain Phi[px] . w - ysub y straight from the
+// accumulators, Phi itself never written (hpc/display.c:60-78 fused into hpc/nystroem.c:41-42)
+struct BandFilter {
+    const float *w = nullptr; // [ld] filter weights x c (device)
+    float gain = 0.f, ysub = 0.f;
+    uint8_t *out = nullptr;   // [N] (absolute pixel index)
+    float *zf = nullptr;      // [N] or null
+    float *corr = nullptr;    // [pix1 - pix0] or null
+};
+// GLF_ERR_UNSUPPORTED: the band form does not apply (not a tensor grid, radius too large, or auto mode prefers a factored form)
+int nystroem_band_filter(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1, const float4 *d_samples,
+                         const uint8_t *d_mask, const uint32_t *d_idx, unsigned p, KernelCoef coef, const float *d_psi, unsigned ld,
+                         const BandFilter &flt, float *kernel_ms, uint64_t *entries_evaluated, double *mfma_flops, int *path,
+                         RowpassStats *stats);
+// c = Psi^T (ysum - t) + Phi_A^T y_A  (ysum: the degree stage's value-weighted sums over all pixels; t = K_A y_A takes the
+// sample pixels out again): Phi^T y without Phi. d_c [ld] f64.
+int c_from_ysum(glf_ctx *ctx, const float *d_psi, const float *d_phiA, const double *d_ysum, const float *d_t, unsigned t_ld,
+                const float4 *d_samples, unsigned p, unsigned ld, double *d_c);
+// the sample pixels' outputs from their rows of Phi_A (the band kernel filters every pixel with its extended row)
+int filter_sample_rows(glf_ctx *ctx, const float *d_phiA, unsigned n, unsigned ld, const uint32_t *d_idx, const uint8_t *d_img,
+                       const float *d_w, float gain, float ysub, uint8_t *d_out, float *d_zf, float *d_corr, int64_t pix0);
 int grid_op_path(const GridOp *op);                          // glf_stats.matvec_path: 1 exact grid form, 3 rank form
 int grid_op_apply(glf_ctx *ctx, GridOp *op, const float *X, float *Y, unsigned ld, double alpha, const double *d_degree,
                   unsigned row0, unsigned row1, int window);

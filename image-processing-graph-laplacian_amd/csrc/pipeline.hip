@@ -25,6 +25,13 @@ static int allreduce_f64(glf_ctx *ctx, double *d, size_t n)
 }
 
 // Psi[i][j] = scale * Phi_A[i][j] * pinv[j]   (part_lower = phi_A * Pi^-1, hpc/nystroem.c:41; scale = -alpha)
+// X[s][0] = y_s (the sample's pixel value) in a block of `ld` columns (the others stay zero)
+__global__ void k_sample_values_column(const float4 *__restrict__ samples, unsigned p, unsigned ld, float *__restrict__ X)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < p) X[(size_t)s * ld] = samples[s].z;
+}
+
 __global__ void k_make_psi(const float *__restrict__ phiA, const float *__restrict__ pinv, unsigned p, unsigned ld, unsigned m,
                            float scale, float *__restrict__ psi)
 {
@@ -534,11 +541,12 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     // ---- affinity: sample tables + degree (K_B generated on the fly) -------------------------
     SampleTables tb;
     GLF_TRY(build_sample_tables(ctx, d_img, width, height, p, h_idx, tb));
-    DevBuf<double> deg;
-    GLF_TRY(deg.alloc(ctx, p));
+    DevBuf<double> deg; // D_A [p], then (grid-factored degree only) the value-weighted sums U[s] = sum_px K(s, px) y[px] [p]
+    GLF_TRY(deg.alloc(ctx, 2 * (size_t)p));
+    bool have_ysum = false;
     GLF_TRY(degree_rows_auto(ctx, d_img, width, height, row0, row1, tb.samples.p, p, h_idx, coef, deg.p, opt.skip_exact_zeros,
-                             &S.degree_evaluated, tb.idx.p));
-    GLF_TRY(allreduce_f64(ctx, deg.p, p));
+                             &S.degree_evaluated, tb.idx.p, deg.p + p, &have_ysum));
+    GLF_TRY(allreduce_f64(ctx, deg.p, have_ysum ? 2 * (size_t)p : p));
     GLF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     if (cap) {
         cap->ld = ld;
@@ -725,36 +733,82 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
                        (float)(-alpha), psi.p);
     GLF_LAUNCH_CHECK(ctx);
     const int64_t npix = pix1 - pix0;
-    GLF_TRY(phi.alloc(ctx, (size_t)npix * ld));
-    float *phi_base = phi.p - (size_t)pix0 * ld; // rows addressed by absolute pixel index
-    GLF_HIP(ctx, hipMemsetAsync(c.p, 0, sizeof(double) * ld, st));
     float kms = 0.f;
     uint64_t evaluated = 0;
     RowpassStats rps;
+    auto nystroem_stats = [&]() {
+        S.nystroem_rowpass_launches = rps.launches;
+        S.nystroem_rowpass_ms = rps.ms;
+        S.nystroem_rowpass_flops = rps.flops;
+        S.nystroem_colpass_launches = rps.col_launches;
+        S.nystroem_colpass_ms = rps.col_ms;
+        S.nystroem_colpass_flops = rps.col_flops;
+        S.rank_terms = rps.rank_R;
+        S.nystroem_launches = 1;
+        S.nystroem_kernel_ms = kms;
+        S.contraction = ctx->contraction;
+        S.skip_exact_zeros = opt.skip_exact_zeros;
+        S.nystroem_evaluated = (double)evaluated; // kernel entries generated (listed chunks x 64 x workgroup pixels)
+    };
+    unsigned si0 = 0, si1 = 0; // the samples among this shard's pixels
+    while (si0 < p && (int64_t)h_idx[si0] < pix0) ++si0;
+    si1 = si0;
+    while (si1 < p && (int64_t)h_idx[si1] < pix1) ++si1;
+    // ---- band form with the filter in the kernel's epilogue: Phi is never written -----------------------------------------
+    // c = Phi^T y is needed before the extension then: it follows from the degree stage's value-weighted sums (c_from_ysum).
+    bool fused = false;
+    if (have_ysum && gop.op && ld <= 64 && opt.filter_mode != GLF_FILTER_SHARPEN && !(cap && cap->d_phi) &&
+        ctx->contraction == GLF_CONTRACT_F16_SPLIT && (ctx->tune.nys_path == 0 || ctx->tune.nys_path == 4) && !ctx->tune.no_fused_filter) {
+        // t = K_A y_A (the sample pixels' share of the sums over all pixels): one 32-column application of the operator
+        DevBuf<float> ya, t;
+        DevBuf<double> zdeg;
+        GLF_TRY(ya.alloc(ctx, (size_t)p32 * 32));
+        GLF_TRY(t.alloc(ctx, (size_t)p32 * 32));
+        GLF_TRY(zdeg.alloc(ctx, p));
+        GLF_HIP(ctx, hipMemsetAsync(ya.p, 0, sizeof(float) * (size_t)p32 * 32, st));
+        GLF_HIP(ctx, hipMemsetAsync(t.p, 0, sizeof(float) * (size_t)p32 * 32, st));
+        GLF_HIP(ctx, hipMemsetAsync(zdeg.p, 0, sizeof(double) * p, st));
+        hipLaunchKernelGGL(k_sample_values_column, dim3((p + 255) / 256), dim3(256), 0, st, tb.samples.p, p, 32u, ya.p);
+        GLF_LAUNCH_CHECK(ctx);
+        GLF_TRY(grid_op_apply(ctx, gop.op, ya.p, t.p, 32, -1.0, zdeg.p, 0, p, 0)); // -(0 X - K_A X) = K_A y_A
+        GLF_TRY(c_from_ysum(ctx, psi.p, phiA.p, deg.p + p, t.p, 32, tb.samples.p, p, ld, c.p));
+        std::vector<double> hc(ld);
+        GLF_HIP(ctx, hipMemcpyAsync(hc.data(), c.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+        if (cap && cap->h_c) std::memcpy(cap->h_c, hc.data(), sizeof(double) * ld);
+        std::vector<float> hw(ld, 0.f);
+        for (unsigned j = 0; j < m; ++j) hw[j] = (float)(filter_weight(lam[j]) * hc[j]);
+        GLF_HIP(ctx, hipMemcpyAsync(w.p, hw.data(), sizeof(float) * ld, hipMemcpyHostToDevice, st));
+        GLF_HIP(ctx, hipStreamSynchronize(st));
+        BandFilter flt;
+        flt.w = w.p;
+        flt.gain = filter_gain;
+        flt.ysub = filter_ysub;
+        flt.out = d_out;
+        flt.zf = d_zf;
+        flt.corr = cap ? cap->d_corr : nullptr;
+        const int rc = nystroem_band_filter(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, psi.p, ld, flt, &kms,
+                                            &evaluated, &S.nystroem_mfma_flops, &S.nystroem_path, &rps);
+        if (rc == GLF_OK) {
+            GLF_TRY(filter_sample_rows(ctx, phiA.p + (size_t)si0 * ld, si1 - si0, ld, tb.idx.p + si0, d_img, w.p, filter_gain, filter_ysub, d_out,
+                                       d_zf, cap ? cap->d_corr : nullptr, pix0));
+            nystroem_stats();
+            S.filter_fused = 1;
+            GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));
+            fused = true;
+        } else if (rc != GLF_ERR_UNSUPPORTED) return rc;
+    }
+    if (!fused) {
+    GLF_TRY(phi.alloc(ctx, (size_t)npix * ld));
+    float *phi_base = phi.p - (size_t)pix0 * ld; // rows addressed by absolute pixel index
+    GLF_HIP(ctx, hipMemsetAsync(c.p, 0, sizeof(double) * ld, st));
     GLF_TRY(nystroem_contract(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, (float)(-alpha),
                               psi.p, m, ld, phi_base, 1, c.p, &kms, opt.skip_exact_zeros, &evaluated, &S.nystroem_mfma_flops,
                               &S.nystroem_path, &rps));
-    S.nystroem_rowpass_launches = rps.launches;
-    S.nystroem_rowpass_ms = rps.ms;
-    S.nystroem_rowpass_flops = rps.flops;
-    S.nystroem_colpass_launches = rps.col_launches;
-    S.nystroem_colpass_ms = rps.col_ms;
-    S.nystroem_colpass_flops = rps.col_flops;
-    S.rank_terms = rps.rank_R;
-    S.nystroem_launches = 1;
-    S.nystroem_kernel_ms = kms;
-    S.contraction = ctx->contraction;
-    S.skip_exact_zeros = opt.skip_exact_zeros;
-    S.nystroem_evaluated = (double)evaluated; // kernel entries generated (listed chunks x 64 x workgroup pixels)
-    {
-        // sample rows of this shard <- Phi_A, and their share of c
-        unsigned i0 = 0, i1 = 0;
-        while (i0 < p && (int64_t)h_idx[i0] < pix0) ++i0;
-        i1 = i0;
-        while (i1 < p && (int64_t)h_idx[i1] < pix1) ++i1;
-        if (i1 > i0)
-            GLF_TRY(scatter_sample_rows(ctx, phiA.p + (size_t)i0 * ld, i1 - i0, ld, tb.idx.p + i0, phi_base, 1, d_img, c.p, m));
-    }
+    nystroem_stats();
+    // sample rows of this shard <- Phi_A, and their share of c
+    if (si1 > si0)
+        GLF_TRY(scatter_sample_rows(ctx, phiA.p + (size_t)si0 * ld, si1 - si0, ld, tb.idx.p + si0, phi_base, 1, d_img, c.p, m));
     GLF_TRY(allreduce_f64(ctx, c.p, ld)); // right = phi^T y over all ranks' pixels
     GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));
     // ---- filter ------------------------------------------------------------------------------
@@ -794,6 +848,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         GLF_HIP(ctx, hipStreamSynchronize(st));
     }
     GLF_TRY(apply_filter(ctx, d_img, phi_base, pix0, pix1, m, ld, w.p, filter_gain, filter_ysub, d_out, d_zf, cap ? cap->d_corr : nullptr));
+    } // (!fused)
     GLF_HIP(ctx, hipEventRecord(ctx->ev[5], st));
     GLF_HIP(ctx, hipEventSynchronize(ctx->ev[5]));
     GLF_HIP(ctx, hipEventElapsedTime(&S.ms_affinity, ctx->ev[0], ctx->ev[1]));

@@ -91,7 +91,7 @@ class Stats(C.Structure):
         ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("matvec_path", C.c_int32),
         ("nystroem_rowpass_launches", C.c_int32), ("nystroem_rowpass_ms", C.c_float), ("nystroem_rowpass_flops", C.c_double),
         ("nystroem_colpass_launches", C.c_int32), ("nystroem_colpass_ms", C.c_float), ("nystroem_colpass_flops", C.c_double),
-        ("rank_terms", C.c_int32), ("reserved_", C.c_int32),
+        ("rank_terms", C.c_int32), ("filter_fused", C.c_int32),
     ]
 
 
@@ -393,7 +393,7 @@ class Context:
     def synchronize(self):
         self._check(_lib.glf_ctx_synchronize(self._ctx))
 
-    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "GS", "RESIDUAL", "VERBOSE")
+    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "GS", "RESIDUAL", "VERBOSE")
 
     def set_tuning(self, **kw):
         """glf_ctx_set_tuning: e.g. set_tuning(NYS_PATH="grid", MV_PATH="dense"); None / "" / "auto" = the default choice."""
@@ -711,7 +711,7 @@ class Context:
                     nystroem_mfma_flops=st.nystroem_mfma_flops, nystroem_path=st.nystroem_path, matvec_path=st.matvec_path,
                     nystroem_rowpass_launches=st.nystroem_rowpass_launches, nystroem_rowpass_ms=st.nystroem_rowpass_ms,
                     nystroem_rowpass_flops=st.nystroem_rowpass_flops, nystroem_colpass_launches=st.nystroem_colpass_launches,
-                    nystroem_colpass_ms=st.nystroem_colpass_ms, nystroem_colpass_flops=st.nystroem_colpass_flops, rank_terms=st.rank_terms,
+                    nystroem_colpass_ms=st.nystroem_colpass_ms, nystroem_colpass_flops=st.nystroem_colpass_flops, rank_terms=st.rank_terms, filter_fused=st.filter_fused,
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     narrow_sweeps=st.eig.narrow_sweeps,
                     eigvals=lam[:st.m].copy())

@@ -462,7 +462,17 @@ def test_end_to_end_with_band_form_forced(ctx, golden, png, name, ns, m, eps):
                                          want_float=True)
     if info["contraction"] == glf.CONTRACT_F16_SPLIT:
         assert info["nystroem_path"] == 4 and info["matvec_path"] == 4
+        assert info["filter_fused"] == (1 if m <= 64 else 0)   # the filter in k_band's epilogue, Phi never written (one block of <= 64 columns)
     _assert_end_to_end(img, ns, m, eps, out.cpu().numpy(), zf.cpu().numpy(), info)
+    if info["contraction"] == glf.CONTRACT_F16_SPLIT and m <= 64:
+        # the same run with Phi written and the filter as its own stage: equal up to the order of the f32 sums
+        ctx.set_tuning(NO_FUSED_FILTER="1")
+        out2, zf2, info2 = ctx.image_processing(ctx.to_device(img), glf.default_options(num_samples=ns, num_eigvals=m, epsilon=eps),
+                                                want_float=True)
+        ctx.set_tuning(NO_FUSED_FILTER=None)
+        assert info2["filter_fused"] == 0 and info2["nystroem_path"] == 4
+        assert float((zf2 - zf).abs().max()) <= 2e-4
+        assert int((out2.int() - out.int()).abs().max()) <= 1
 
 
 @pytest.mark.parametrize("rowpass", ["default", "v1", "rt"])
