@@ -567,7 +567,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     // L_A[:, r0:r1) (= its row block transposed; L_A is symmetric) and computes rows [r0,r1) of every
     // mat-vec. Otherwise (single GPU, f32 contraction, or no allgather callback) L_A is whole.
     MatShard shard;
-    const bool shard_eig = ctx->has_comm && ctx->comm.allgather_f32 && ctx->contraction == GLF_CONTRACT_F16_SPLIT && !wide;
+    bool shard_eig = ctx->has_comm && ctx->comm.allgather_f32 && ctx->contraction == GLF_CONTRACT_F16_SPLIT && !wide;
     // For a tensor-grid sample set L_A is applied in grid-factored form and never stored (GLF_MV_PATH = grid | dense | auto;
     // auto: from 16 384 samples on -- below, streaming a small stored L_A is cheaper than the factored sweep's fixed cost)
     struct GridOpGuard {
@@ -582,6 +582,12 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         }
     }
     S.matvec_path = gop.op ? grid_op_path(gop.op) : 0;
+    // With the band form a sweep costs less (0.19 ms at cfg4) than the all-gather of its 21.8 MB operand block over xGMI
+    // (~0.2-0.4 ms), and the whole eigen-solve (4.8 ms) less than the sharded one's 12 all-gathers + ~46 small all-reduces:
+    // every rank then runs the eigen-solve on all rows (bit-identical to one GPU, no collective) and only the pixel rows
+    // -- degree, extension, filter -- are sharded. EIG_SHARD=1 forces the row-sharded solve, 0 the replicated one.
+    if (shard_eig && ((S.matvec_path == 4 && ctx->tune.eig_shard != 1) || ctx->tune.eig_shard == 2)) shard_eig = false;
+    S.eigen_sharded = shard_eig ? 1 : 0;
     if (gop.op) {
         shard.grid = gop.op;
         shard.grid_alpha = alpha;

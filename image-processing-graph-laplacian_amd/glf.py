@@ -91,7 +91,7 @@ class Stats(C.Structure):
         ("nystroem_mfma_flops", C.c_double), ("nystroem_path", C.c_int32), ("matvec_path", C.c_int32),
         ("nystroem_rowpass_launches", C.c_int32), ("nystroem_rowpass_ms", C.c_float), ("nystroem_rowpass_flops", C.c_double),
         ("nystroem_colpass_launches", C.c_int32), ("nystroem_colpass_ms", C.c_float), ("nystroem_colpass_flops", C.c_double),
-        ("rank_terms", C.c_int32), ("filter_fused", C.c_int32),
+        ("rank_terms", C.c_int32), ("filter_fused", C.c_int32), ("eigen_sharded", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -315,7 +315,7 @@ class Multi:
                       residual=s.eig.residual, row0=s.row0, row1=s.row1, ms_total=s.ms_total, ms_eigen=s.ms_eigen,
                       ms_nystroem=s.ms_nystroem, ms_affinity=s.ms_affinity, ms_laplacian=s.ms_laplacian, ms_filter=s.ms_filter,
                       matvecs=s.eig.matvecs, nystroem_path=s.nystroem_path,
-                      matvec_path=s.matvec_path, eigvals=lam[:s.m].copy()) for s in stats]
+                      matvec_path=s.matvec_path, filter_fused=s.filter_fused, eigen_sharded=s.eigen_sharded, eigvals=lam[:s.m].copy()) for s in stats]
         return out, zf, infos
 
     def comm_counters(self, rank=0, reset=True):
@@ -393,7 +393,7 @@ class Context:
     def synchronize(self):
         self._check(_lib.glf_ctx_synchronize(self._ctx))
 
-    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "GS", "RESIDUAL", "VERBOSE")
+    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "EIG_SHARD", "GS", "RESIDUAL", "VERBOSE")
 
     def set_tuning(self, **kw):
         """glf_ctx_set_tuning: e.g. set_tuning(NYS_PATH="grid", MV_PATH="dense"); None / "" / "auto" = the default choice."""
@@ -711,7 +711,7 @@ class Context:
                     nystroem_mfma_flops=st.nystroem_mfma_flops, nystroem_path=st.nystroem_path, matvec_path=st.matvec_path,
                     nystroem_rowpass_launches=st.nystroem_rowpass_launches, nystroem_rowpass_ms=st.nystroem_rowpass_ms,
                     nystroem_rowpass_flops=st.nystroem_rowpass_flops, nystroem_colpass_launches=st.nystroem_colpass_launches,
-                    nystroem_colpass_ms=st.nystroem_colpass_ms, nystroem_colpass_flops=st.nystroem_colpass_flops, rank_terms=st.rank_terms, filter_fused=st.filter_fused,
+                    nystroem_colpass_ms=st.nystroem_colpass_ms, nystroem_colpass_flops=st.nystroem_colpass_flops, rank_terms=st.rank_terms, filter_fused=st.filter_fused, eigen_sharded=st.eigen_sharded,
                     matvecs=st.eig.matvecs, matvec_ms=st.eig.matvec_ms, matvec_bytes=st.eig.matvec_bytes,
                     narrow_sweeps=st.eig.narrow_sweeps,
                     eigvals=lam[:st.m].copy())

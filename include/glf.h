@@ -66,7 +66,7 @@ int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *nu
  * row-pass shapes, ...); the default picks by problem size. key / value (value NULL, "" or "auto" = default):
  *   NYS_PATH  band | rank | grid | direct     DEG_PATH  grid | direct     MV_PATH  band | rank | grid | dense
  *   ROWPASS, ROWPASS_OP  rt | v1     COLPASS  ws | v1     SWEEP_COLPASS  segments | samples
- *   NYS_NO_LUT, NO_ECR, NO_NARROW, NO_FUSED_FILTER, VERBOSE  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
+ *   NYS_NO_LUT, NO_ECR, NO_NARROW, NO_FUSED_FILTER, VERBOSE  1 | 0     EIG_SHARD  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
  * At context creation each key is initialised from the environment variable GLF_<KEY> (read once; nothing reads the
  * environment per call). No reference counterpart (PETSc's -ksp_type / -pc_type options database is the nearest thing). */
 int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value);
@@ -371,6 +371,10 @@ typedef struct glf_stats {
     /* 1: the filter ran in the epilogue of the band-form Nystroem kernel (Phi never written; c = Phi^T y from the degree stage's
      * value-weighted sums); ms_filter is then part of ms_nystroem. 0: Phi written, filter as its own stage */
     int32_t filter_fused;
+    /* under a communicator: 1 the eigen-solve ran row-sharded (all-gather of the operand per L_A application, all-reduced inner
+     * products), 0 every rank ran it on all rows (the default with the band form, whose sweep is cheaper than its all-gather) */
+    int32_t eigen_sharded;
+    int32_t reserved_;
 } glf_stats;
 
 /* ApproximationComputation, hpc/image_processing.c:183-277 (commented tail

@@ -55,6 +55,23 @@ def test_loopback_ranks_on_one_device_match_single_context(n, paths, monkeypatch
     _check(img, opt, n, glf.MULTI_LOOPBACK, [0] * n)
 
 
+def test_band_form_replicates_the_eigen_solve_unless_told_otherwise(monkeypatch):
+    """With the band form every rank runs the eigen-solve on all rows by default (a sweep costs less than the all-gather of its
+    operand; glf_stats.eigen_sharded = 0) and only the pixel rows are sharded; GLF_EIG_SHARD=1 keeps the row-sharded solve with
+    its collectives, =0 replicates it for the factored forms too. All against the single-context result."""
+    img = glf.synth_image(96, 80, seed=4)
+    opt = glf.default_options(num_samples=60, num_eigvals=8, epsilon=0.05)
+    for paths, env, want in (("band", None, 0), ("band", "1", 1), ("rank", None, 1), ("rank", "0", 0)):
+        _env_paths(monkeypatch, paths)
+        if env is None:
+            monkeypatch.delenv("GLF_EIG_SHARD", raising=False)
+        else:
+            monkeypatch.setenv("GLF_EIG_SHARD", env)
+        infos = _check(img, opt, 3, glf.MULTI_LOOPBACK, [0] * 3)
+        assert [i["eigen_sharded"] for i in infos] == [want] * 3, (paths, env)
+    monkeypatch.delenv("GLF_EIG_SHARD", raising=False)
+
+
 def test_loopback_more_ranks_than_grid_rows_and_odd_shards(monkeypatch):
     """5 ranks on a 53 x 37 image (p = 24: a 4 x 6 sample grid -- fewer grid rows than ranks, so some ranks own no row of the
     eigen-solve; image row shards of 7 or 8 rows) in both kernel families."""
