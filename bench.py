@@ -660,9 +660,11 @@ def main():
                        "image_crc32": "%08x" % crc,
                        "psnr_reference": "PETSc/SLEPc are not installable here (SURVEY 8c): PSNR is against the fp64 restatement of "
                                          "hpc/*.c, see cpu_baseline.parity_headline (this run, sampled rows) and .parity_cfg2 (whole image)",
-                       "sharding": "pixel rows / %d ranks; eigen-solve rows / %d ranks (all-reduce of inner products and Gram blocks, "
-                                   "all-gather of the operand per L_A application); collectives: %s" %
-                                   (n_gpus, n_gpus, "none" if n_gpus == 1 and not args.force_comm else
+                       "sharding": "pixel rows / %d ranks; eigen-solve %s; collectives: %s" %
+                                   (n_gpus, ("rows / %d ranks (all-reduce of inner products and Gram blocks, all-gather of the operand per L_A "
+                                             "application)" % n_gpus) if info.get("eigen_sharded", 0) or n_gpus == 1 else
+                                    "replicated on every rank (band form: a sweep costs less than the all-gather of its operand; one all-reduce "
+                                    "of D_A and the value-weighted sums per image)", "none" if n_gpus == 1 and not args.force_comm else
                                     ("RCCL issued by the library" if args.comm == "rccl" else "torch.distributed callbacks"))},
             "stage_ms_rank0": stage_ms,
             "filter_fused": bool(info.get("filter_fused", 0)),
