@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--no-skip-leg", action="store_true",
                     help="do not time the extra exact-zero-skipping leg (reported beside the headline)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-nlm-leg", action="store_true",
+                    help="skip the non-local-means leg (1024^2, 0.5 % samples, m = 64: the f1 affinity through the whole path)")
     ap.add_argument("--no-batch-leg", action="store_true",
                     help="skip the throughput-mode leg (BASELINE config 5: 64 tiles of 1024x1024 dealt to concurrent contexts)")
     ap.add_argument("--batch-tiles", type=int, default=64)
@@ -475,6 +477,33 @@ def main():
         cap_run = ctx.image_processing(d_img, opt, want_float=True, capture=True)
         info["capture"] = cap_run[2]["capture"]
 
+    # nlm leg: the non-local-means affinity (python/affinity_methods/NLM.py) through the whole path on one 1024^2 tile; its K has
+    # no factored or banded form (patch distances), every one of the p x N entries is generated twice (degree, extension)
+    nlm_leg = None
+    if not args.no_nlm_leg and world == 1:
+        ts = 1024
+        d_nlm = ctx.to_device(glf.synth_image(ts, ts, seed=7))
+        o_nlm = glf.default_options(num_samples=int(ts * ts * args.sample_frac), num_eigvals=args.num_eigvals, epsilon=args.epsilon,
+                                    kernel=glf.KERNEL_NLM, h_val=3.0)
+        ctx.image_processing(d_nlm, o_nlm)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, _, ninfo = ctx.image_processing(d_nlm, o_nlm)
+        barrier()
+        n_sec = (time.perf_counter() - t0) / args.steps
+        entries = float(ninfo["p"]) * ts * ts
+        nlm_leg = {"workload": "1024x1024 synthetic, 0.5%% samples (p=%d), m=%d, non-local-means affinity (7x7 patches, h = 3)" % (ninfo["p"], ninfo["m"]),
+                   "value": round(ts * ts / n_sec * 1e-6, 3), "unit": "Mpixel/s", "ms_per_image": round(n_sec * 1e3, 3),
+                   "stage_ms": {k[3:]: round(ninfo[k], 3) for k in ("ms_affinity", "ms_laplacian", "ms_eigen", "ms_nystroem", "ms_filter")},
+                   "kernel_entries_per_pass": entries,
+                   "degree_gentries_per_s": round(entries / (ninfo["ms_affinity"] * 1e-3) / 1e9, 1),
+                   "nystroem_gentries_per_s": round(entries / (ninfo["ms_nystroem"] * 1e-3) / 1e9, 1),
+                   "bound": "vector pipe + LDS broadcast reads: 49 weighted patch differences per entry (52 packed f32 instructions and 13 "
+                            "ds_read_b128 per wave and entry); the extension's contraction runs on v_mfma_f32_32x32x2_f32",
+                   "note": "a next-row feature (SURVEY 8f f1), not the headline path: no MFMA form of the distances yet (DESIGN section 8)"}
+        del d_nlm
+
     batch_leg = None
     if not args.no_batch_leg:
         batch_leg = run_batch_leg(args, ctx, rank, world, barrier)
@@ -705,6 +734,8 @@ def main():
             }
         if batch_leg is not None:
             line["throughput_mode"] = batch_leg
+        if nlm_leg is not None:
+            line["nlm"] = nlm_leg
         if direct_leg is not None:
             d_ms = direct_leg["nystroem_kernel_ms"]
             d_tf = flops / (d_ms * 1e-3) / 1e12

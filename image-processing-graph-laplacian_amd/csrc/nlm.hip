@@ -87,21 +87,26 @@ __device__ __forceinline__ void nlm_stage(const uint8_t *__restrict__ img, int w
     }
 }
 
-// || f - row ||^2 with `row` a feature row in LDS (wave-wide broadcast reads of 13 float4)
+// || f - row ||^2 with `row` a feature row in LDS (wave-wide broadcast reads of 13 float4). Two terms per instruction
+// (v_pk_add_f32 / v_pk_fma_f32 on register pairs, two accumulators: even and odd terms): 52 vector instructions per entry
+// instead of 98 -- these kernels have no MFMA burst for the packed forms to get in the way of (beside MFMAs they measured
+// slower than scalar ones, k_nystroem_f16s).
+typedef float nlm_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float nlm_dist(const float (&f)[NLM_K], const float *row)
 {
-    float d = 0.f;
+    nlm_f32x2 d = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const float4 x = *reinterpret_cast<const float4 *>(row + 4 * q);
-        const float e0 = f[4 * q] - x.x, e1 = f[4 * q + 1] - x.y, e2 = f[4 * q + 2] - x.z, e3 = f[4 * q + 3] - x.w;
-        d = fmaf(e0, e0, d);
-        d = fmaf(e1, e1, d);
-        d = fmaf(e2, e2, d);
-        d = fmaf(e3, e3, d);
+        nlm_f32x2 a0 = {f[4 * q], f[4 * q + 1]}, a1 = {f[4 * q + 2], f[4 * q + 3]};
+        const nlm_f32x2 x0 = {x.x, x.y}, x1 = {x.z, x.w};
+        a0 -= x0;
+        a1 -= x1;
+        d = __builtin_elementwise_fma(a0, a0, d);
+        d = __builtin_elementwise_fma(a1, a1, d);
     }
     const float e = f[48] - row[48];
-    return fmaf(e, e, d);
+    return fmaf(e, e, d[0] + d[1]);
 }
 
 // ---- degree -------------------------------------------------------------------------------------------------------------
