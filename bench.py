@@ -499,8 +499,8 @@ def main():
                    "kernel_entries_per_pass": entries,
                    "degree_gentries_per_s": round(entries / (ninfo["ms_affinity"] * 1e-3) / 1e9, 1),
                    "nystroem_gentries_per_s": round(entries / (ninfo["ms_nystroem"] * 1e-3) / 1e9, 1),
-                   "bound": "vector pipe + LDS broadcast reads: 49 weighted patch differences per entry (52 packed f32 instructions and 13 "
-                            "ds_read_b128 per wave and entry); the extension's contraction runs on v_mfma_f32_32x32x2_f32",
+                   "bound": "vector pipe: 49 weighted patch differences per entry (~100 f32 issue slots per wave and entry; the packed forms issue "
+                            "at half rate); the extension's contraction runs on v_mfma_f32_32x32x2_f32",
                    "note": "a next-row feature (SURVEY 8f f1), not the headline path: no MFMA form of the distances yet (DESIGN section 8)"}
         del d_nlm
 

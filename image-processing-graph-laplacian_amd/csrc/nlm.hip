@@ -89,8 +89,11 @@ __device__ __forceinline__ void nlm_stage(const uint8_t *__restrict__ img, int w
 
 // || f - row ||^2 with `row` a feature row in LDS (wave-wide broadcast reads of 13 float4). Two terms per instruction
 // (v_pk_add_f32 / v_pk_fma_f32 on register pairs, two accumulators: even and odd terms): 52 vector instructions per entry
-// instead of 98 -- these kernels have no MFMA burst for the packed forms to get in the way of (beside MFMAs they measured
-// slower than scalar ones, k_nystroem_f16s).
+// instead of 98. It bought 3 %: v_pk_add_f32 / v_pk_fma_f32 issue at half the rate of their scalar forms on this part, so the
+// passes stay bound by the vector pipe at ~100 issue slots per entry (5.6e9 entries x 100 x 4 cycles / 1024 SIMDs = 14 ms at
+// 1024^2, what the degree pass takes); sharing a feature row between two patches per lane (half the LDS reads) changed nothing
+// either. Halving the work takes the dot-product form || a ||^2 + || b ||^2 - 2 a.b, whose f32 cancellation (~5e-5 absolute
+// in d^2, 6e-6 relative in K) sits at the degree test's 3e-6 bound: not taken.
 typedef float nlm_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float nlm_dist(const float (&f)[NLM_K], const float *row)
 {
