@@ -32,6 +32,14 @@ __global__ void k_sample_values_column(const float4 *__restrict__ samples, unsig
     if (s < p) X[(size_t)s * ld] = samples[s].z;
 }
 
+// t[s][0] = D_s y_s - t[s][0] / alpha: K_A y_A from (L_A y_A) with L_A = alpha (D - K_A)
+__global__ void k_ka_from_la(const float4 *__restrict__ samples, const double *__restrict__ degree, unsigned p, unsigned ld, double inv_alpha,
+                             float *__restrict__ T)
+{
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < p) T[(size_t)s * ld] = (float)(degree[s] * (double)samples[s].z - (double)T[(size_t)s * ld] * inv_alpha);
+}
+
 __global__ void k_make_psi(const float *__restrict__ phiA, const float *__restrict__ pinv, unsigned p, unsigned ld, unsigned m,
                            float scale, float *__restrict__ psi)
 {
@@ -716,7 +724,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
                                          (shard_eig || shard.kbox || shard.grid) ? &shard : nullptr, dinv.p, d_x0);
         if (rc != GLF_OK) return rc;
     }
-    LA.release();
+    if (shard_eig || gop.op) LA.release(); // (a whole stored L_A is used once more below: K_A y_A for the fused filter)
     if (cap && cap->d_phi_A) GLF_HIP(ctx, hipMemcpyAsync(cap->d_phi_A, phiA.p, sizeof(float) * (size_t)p32 * ld, hipMemcpyDeviceToDevice, st));
     if (eigvals_out)
         for (unsigned j = 0; j < m; ++j) eigvals_out[j] = lam[j];
@@ -763,7 +771,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
     // ---- band form with the filter in the kernel's epilogue: Phi is never written -----------------------------------------
     // c = Phi^T y is needed before the extension then: it follows from the degree stage's value-weighted sums (c_from_ysum).
     bool fused = false;
-    if (have_ysum && gop.op && ld <= 64 && opt.filter_mode != GLF_FILTER_SHARPEN && !(cap && cap->d_phi) &&
+    if (have_ysum && (gop.op || LA.p) && ld <= 64 && opt.filter_mode != GLF_FILTER_SHARPEN && !(cap && cap->d_phi) &&
         ctx->contraction == GLF_CONTRACT_F16_SPLIT && (ctx->tune.nys_path == 0 || ctx->tune.nys_path == 4) && !ctx->tune.no_fused_filter) {
         // t = K_A y_A (the sample pixels' share of the sums over all pixels): one 32-column application of the operator
         DevBuf<float> ya, t;
@@ -776,7 +784,12 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         GLF_HIP(ctx, hipMemsetAsync(zdeg.p, 0, sizeof(double) * p, st));
         hipLaunchKernelGGL(k_sample_values_column, dim3((p + 255) / 256), dim3(256), 0, st, tb.samples.p, p, 32u, ya.p);
         GLF_LAUNCH_CHECK(ctx);
-        GLF_TRY(grid_op_apply(ctx, gop.op, ya.p, t.p, 32, -1.0, zdeg.p, 0, p, 0)); // -(0 X - K_A X) = K_A y_A
+        if (gop.op) GLF_TRY(grid_op_apply(ctx, gop.op, ya.p, t.p, 32, -1.0, zdeg.p, 0, p, 0)); // -(0 X - K_A X) = K_A y_A
+        else { // stored L_A = alpha (D - K_A): K_A y_A = D y_A - L_A y_A / alpha
+            GLF_TRY(block_matvec(ctx, LA.p, lda, p, ya.p, t.p, 32, shard.kbox ? &shard : nullptr));
+            hipLaunchKernelGGL(k_ka_from_la, dim3((p + 255) / 256), dim3(256), 0, st, tb.samples.p, deg.p, p, 32u, 1.0 / alpha, t.p);
+            GLF_LAUNCH_CHECK(ctx);
+        }
         GLF_TRY(c_from_ysum(ctx, psi.p, phiA.p, deg.p + p, t.p, 32, tb.samples.p, p, ld, c.p));
         std::vector<double> hc(ld);
         GLF_HIP(ctx, hipMemcpyAsync(hc.data(), c.p, sizeof(double) * ld, hipMemcpyDeviceToHost, st));
@@ -804,6 +817,7 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
             fused = true;
         } else if (rc != GLF_ERR_UNSUPPORTED) return rc;
     }
+    LA.release();
     if (!fused) {
     GLF_TRY(phi.alloc(ctx, (size_t)npix * ld));
     float *phi_base = phi.p - (size_t)pix0 * ld; // rows addressed by absolute pixel index
