@@ -103,7 +103,7 @@ constexpr int NYS_PAD = 64; // sample table and Psi are zero-padded to a multipl
 
 // pinned page layout (bytes): [0] PCG active-column counter (int), [64] Gram-Schmidt fallback flag (int),
 // [128 .. 128 + 8 * 256) residual column sums (double[ld <= 256]), [3072] largest segment count of a row (rank form)
-constexpr size_t PINNED_BYTES = 4096, PINNED_NACTIVE = 0, PINNED_GSFLAG = 64, PINNED_SUMS = 128, PINNED_RANKSEG = 3072;
+constexpr size_t PINNED_BYTES = 4096, PINNED_NACTIVE = 0, PINNED_GSFLAG = 64, PINNED_SUMS = 128, PINNED_RANKSEG = 3072, PINNED_BANDEVAL = 3136;
 inline char *ctx_pinned(glf_ctx *ctx)
 {
     if (!ctx->pinned && hipHostMalloc(&ctx->pinned, PINNED_BYTES, hipHostMallocDefault) != hipSuccess) ctx->pinned = nullptr;
@@ -344,7 +344,7 @@ struct BandFilter {
 int nystroem_band_filter(glf_ctx *ctx, const uint8_t *d_img, int width, int height, int64_t pix0, int64_t pix1, const float4 *d_samples,
                          const uint8_t *d_mask, const uint32_t *d_idx, unsigned p, KernelCoef coef, const float *d_psi, unsigned ld,
                          const BandFilter &flt, float *kernel_ms, uint64_t *entries_evaluated, double *mfma_flops, int *path,
-                         RowpassStats *stats);
+                         RowpassStats *stats, const unsigned *h_idx = nullptr); // h_idx: the host copy of d_idx when the caller has it
 // c = Psi^T (ysum - t) + Phi_A^T y_A  (ysum: the degree stage's value-weighted sums over all pixels; t = K_A y_A takes the
 // sample pixels out again): Phi^T y without Phi. d_c [ld] f64.
 int c_from_ysum(glf_ctx *ctx, const float *d_psi, const float *d_phiA, const double *d_ysum, const float *d_t, unsigned t_ld,

@@ -806,11 +806,13 @@ int glf_image_processing_capture(glf_ctx *ctx, const glf_options *opt_in, const 
         flt.out = d_out;
         flt.zf = d_zf;
         flt.corr = cap ? cap->d_corr : nullptr;
+        // the sample pixels from their rows of Phi_A first (k_band leaves them alone: the host work between the two launches --
+        // grid detection, cached tables -- then overlaps a kernel instead of following the long one)
+        GLF_TRY(filter_sample_rows(ctx, phiA.p + (size_t)si0 * ld, si1 - si0, ld, tb.idx.p + si0, d_img, w.p, filter_gain, filter_ysub, d_out, d_zf,
+                                   cap ? cap->d_corr : nullptr, pix0));
         const int rc = nystroem_band_filter(ctx, d_img, width, height, pix0, pix1, tb.samples.p, tb.mask.p, tb.idx.p, p, coef, psi.p, ld, flt, &kms,
-                                            &evaluated, &S.nystroem_mfma_flops, &S.nystroem_path, &rps);
+                                            &evaluated, &S.nystroem_mfma_flops, &S.nystroem_path, &rps, h_idx);
         if (rc == GLF_OK) {
-            GLF_TRY(filter_sample_rows(ctx, phiA.p + (size_t)si0 * ld, si1 - si0, ld, tb.idx.p + si0, d_img, w.p, filter_gain, filter_ysub, d_out,
-                                       d_zf, cap ? cap->d_corr : nullptr, pix0));
             nystroem_stats();
             S.filter_fused = 1;
             GLF_HIP(ctx, hipEventRecord(ctx->ev[4], st));

@@ -671,7 +671,13 @@ class Context:
                 out = torch.zeros((h, w), dtype=torch.uint8, device=self.device)
             zf = torch.zeros((h, w), dtype=torch.float32, device=self.device) if want_float else None
         st = Stats()
-        p_real = int(Sampling(w, h, int(opt.num_samples) if opt.num_samples else int(h * w * opt.sample_frac)).size)
+        # (the realised sample count sizes the eigenvalue array; hpc/sampling.c's rule, cached per image size and request)
+        req = int(opt.num_samples) if opt.num_samples else int(h * w * opt.sample_frac)
+        key = (w, h, req, int(getattr(opt, "sampling", 0)), int(getattr(opt, "sampling_seed", 0)))
+        cache = self.__dict__.setdefault("_p_real_cache", {})
+        if key not in cache:
+            cache[key] = int(Sampling(w, h, req).size) if not getattr(opt, "sampling", 0) else max(req, 1) * 2 + 64
+        p_real = cache[key]
         lam = np.zeros(max(p_real, 1), dtype=np.float64)       # m <= p - 1 eigenvalues come back
         cap, keep = None, None
         if capture:
