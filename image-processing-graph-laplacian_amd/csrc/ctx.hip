@@ -74,7 +74,7 @@ int glf_ctx_create(glf_ctx **out, int device, void *hip_stream)
         else fprintf(stderr, "glf: ignoring GLF_CONTRACTION=%s (expected f32 or f16s)\n", mode);
     }
     if (const char *dbg = std::getenv("GLF_POOL_DEBUG")) ctx->pool_debug = dbg[0] && dbg[0] != '0';
-    for (const char *key : {"NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "EIG_SHARD", "GS", "RESIDUAL", "VERBOSE"}) {
+    for (const char *key : {"NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "EIG_SHARD", "ZMFMA_GROUPS", "GS", "RESIDUAL", "VERBOSE"}) {
         char name[32];
         std::snprintf(name, sizeof(name), "GLF_%s", key);
         if (const char *v = std::getenv(name))
@@ -114,6 +114,7 @@ int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value)
     else if (!std::strcmp(key, "NO_ECR")) t.no_ecr = flag();
     else if (!std::strcmp(key, "NO_NARROW")) t.no_narrow = flag();
     else if (!std::strcmp(key, "NO_FUSED_FILTER")) t.no_fused_filter = flag();
+    else if (!std::strcmp(key, "ZMFMA_GROUPS")) t.zmfma_groups = flag();
     else if (!std::strcmp(key, "EIG_SHARD")) t.eig_shard = unset ? 0 : is("0") ? 2 : 1;
     else if (!std::strcmp(key, "GS")) {
         if (!unset && !is("seq") && !is("gram")) return GLF_ERR_INVALID;

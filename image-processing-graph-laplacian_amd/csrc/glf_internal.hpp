@@ -38,6 +38,7 @@ struct glf_tuning {
     bool no_ecr = false;         // NO_ECR: column pass reads the per-column Ec fragment table instead of the compact one
     bool gs_seq = false;         // GS=seq: Gram-Schmidt as the column-by-column sweep instead of the Gram-matrix form
     bool residual_sweep = false; // RESIDUAL=sweep: residual from an explicit L_A sweep instead of the PCG state
+    bool zmfma_groups = false;   // ZMFMA_GROUPS: degree row contraction in groups of five m-tiles (two n-tiles per wave) even when ten fit one wave
     int eig_shard = 0;           // EIG_SHARD: 0 auto (row-sharded eigen-solve unless the operator is in band form), 1 sharded, 2 replicated
     bool no_fused_filter = false; // NO_FUSED_FILTER: band form writes Phi and the filter runs as its own stage (k_apply_filter)
     bool no_narrow = false;      // NO_NARROW: block PCG applies the operator to all columns of the block even when few still iterate

@@ -393,7 +393,7 @@ class Context:
     def synchronize(self):
         self._check(_lib.glf_ctx_synchronize(self._ctx))
 
-    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "EIG_SHARD", "GS", "RESIDUAL", "VERBOSE")
+    TUNING_KEYS = ("NYS_PATH", "DEG_PATH", "MV_PATH", "ROWPASS", "ROWPASS_OP", "SWEEP_COLPASS", "COLPASS", "NYS_NO_LUT", "NO_ECR", "NO_NARROW", "NO_FUSED_FILTER", "EIG_SHARD", "ZMFMA_GROUPS", "GS", "RESIDUAL", "VERBOSE")
 
     def set_tuning(self, **kw):
         """glf_ctx_set_tuning: e.g. set_tuning(NYS_PATH="grid", MV_PATH="dense"); None / "" / "auto" = the default choice."""
