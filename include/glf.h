@@ -66,7 +66,7 @@ int glf_ctx_device_info(const glf_ctx *ctx, char *name, size_t name_len, int *nu
  * row-pass shapes, ...); the default picks by problem size. key / value (value NULL, "" or "auto" = default):
  *   NYS_PATH  band | rank | grid | direct     DEG_PATH  grid | direct     MV_PATH  band | rank | grid | dense
  *   ROWPASS, ROWPASS_OP  rt | v1     COLPASS  ws | v1     SWEEP_COLPASS  segments | samples
- *   NYS_NO_LUT, NO_ECR, NO_NARROW, NO_FUSED_FILTER, VERBOSE  1 | 0     EIG_SHARD  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
+ *   NYS_NO_LUT, NO_ECR, NO_NARROW, NO_FUSED_FILTER, ZMFMA_GROUPS, VERBOSE  1 | 0     EIG_SHARD  1 | 0       GS        seq | gram          RESIDUAL  sweep | derived
  * At context creation each key is initialised from the environment variable GLF_<KEY> (read once; nothing reads the
  * environment per call). No reference counterpart (PETSc's -ksp_type / -pc_type options database is the nearest thing). */
 int glf_ctx_set_tuning(glf_ctx *ctx, const char *key, const char *value);
